@@ -1,0 +1,181 @@
+"""Pins oracle/nppc_ref.py (the CPU restatement) against fixtures produced by running the
+reference itself (tests/golden/make_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nppc_ref as R
+from oracle import weights as W
+
+CONFIGS = ["g0_tiny", "g0_tiny_g1", "g1_c1", "g2_k5"]
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.load(open(os.path.join(golden_dir, name + ".json")))
+    return z, meta
+
+
+def weights_for(c):
+    spec = W.nppc_spec(c["K"], num_freqs=c["F"], sb_neighbors=c["sbn"], sb_hidden=c["sbh"])
+    return {k: torch.from_numpy(v) for k, v in W.make_weights(spec, c["seed"]).items()}
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module", params=CONFIGS)
+def run(request, golden_dir):
+    torch.set_num_threads(8)
+    z, meta = load(golden_dir, request.param)
+    c = meta["config"]
+    P = weights_for(c)
+    for k, v in P.items():
+        if k.startswith("audio_pc_wrapper"):
+            v.requires_grad_(True)
+    noisy = torch.from_numpy(z["noisy"])
+    clean = torch.from_numpy(z["clean"])
+    taps = {}
+    out = {}
+    for step in (0, 500):
+        reconst, obj, log = R.nppc_step(noisy, clean, P, c["K"], step, stft=(c["nfft"], c["hop"], c["nfft"]),
+                                        g_rest=c["G_rest"], g_pc=c["G_pc"], sb_neighbors=c["sbn"],
+                                        taps=taps if step == 0 else None)
+        names = [k for k in P if P[k].requires_grad]
+        grads = torch.autograd.grad(obj, [P[k] for k in names], allow_unused=True)
+        out[step] = (reconst, obj, log, dict(zip(names, grads)))
+    return z, meta, c, P, out, taps
+
+
+def test_synth_batch_reproducible(golden_dir):
+    z, meta = load(golden_dir, "g0_tiny")
+    c = meta["config"]
+    noisy, clean = W.synth_batch(c["B"], c["L"])
+    assert np.array_equal(noisy, z["noisy"]) and np.array_equal(clean, z["clean"])
+
+
+def test_front_end(run):
+    z, meta, c, P, out, taps = run
+    parts = out[0][2]["parts"]
+    assert rel(parts["mag"].numpy(), z["noisy_mag"]) < 1e-6
+    assert rel(parts["re"].numpy(), z["noisy_real"]) < 1e-6
+    assert rel(parts["im"].numpy(), z["noisy_imag"]) < 1e-6
+
+
+def test_restorer_and_mask_application(run):
+    z, meta, c, P, out, taps = run
+    log = out[0][2]
+    parts = log["parts"]
+    for tag in ("att_mag", "att_real", "att_imag"):
+        assert rel(taps["rest"][tag].numpy(), z[f"rest.{tag}.out"]) < 2e-5, tag
+    for tag in ("fb_mag", "fb_real", "fb_imag"):
+        assert rel(taps["rest"][tag].numpy(), z[f"rest.{tag}"]) < 2e-4, tag
+    sb = taps["rest"]["sb_in"].numpy()
+    assert list(sb.shape) == meta["rest.sb.in_shape"]
+    assert rel(sb[:8], z["rest.sb.in_head"]) < 2e-4 and rel(sb[-8:], z["rest.sb.in_tail"]) < 2e-4
+    assert abs(sb.astype(np.float64).sum() - meta["rest.sb.in_sum"]) < 2e-4 * meta["rest.sb.in_abs_sum"]
+    assert rel(log["pred_crm_full"].numpy(), z["pred_crm_full"]) < 2e-4
+    assert rel(parts["dec"].permute(0, 2, 3, 1).numpy(), z["pred_crm_decompressed"]) < 2e-4
+    assert rel(parts["emag"].numpy(), z["enh_mag"]) < 2e-4
+    assert rel(parts["ere"].numpy(), z["enh_real"]) < 2e-4
+    assert rel(parts["eim"].numpy(), z["enh_imag"]) < 2e-4
+
+
+def test_direction_net_and_gram_schmidt(run):
+    z, meta, c, P, out, taps = run
+    log = out[0][2]
+    for tag in ("att_mag", "att_real", "att_imag"):
+        got = taps["pc"][tag].detach().numpy()
+        F = c["F"]
+        assert rel(got[:, :F], z[f"pc.{tag}.out"]) < 1e-4, tag
+        assert rel(got[:, F:], z[f"pc.{tag}.out_enh"]) < 1e-4, tag
+    for tag in ("fb_mag", "fb_real", "fb_imag"):
+        assert rel(taps["pc"][tag].detach().numpy(), z[f"pc.{tag}"]) < 5e-4, tag
+    assert rel(log["parts"]["raw"].detach().numpy(), z["pc_raw"]) < 5e-4
+    assert rel(log["w_mat"].numpy(), z["log.w_mat"]) < 5e-4
+    assert rel(log["gt_crm"].numpy(), z["gt_crm"]) < 1e-5
+    assert rel(log["pred_crm"].numpy(), z["pred_crm"]) < 2e-4
+
+
+def test_loss_terms_and_lambda_ramp(run):
+    z, meta, c, P, out, taps = run
+    log = out[0][2]
+    for k in ("err_norm", "err_proj_mag", "w_norms", "reconst_err", "second_moment_mse"):
+        assert rel(log[k].numpy(), z["log." + k]) < 5e-4, k
+    assert rel(log["err_proj"].real.numpy(), z["log.err_proj_re"]) < 5e-4 or \
+        np.abs(log["err_proj"].real.numpy() - z["log.err_proj_re"]).max() < 5e-5
+    assert abs(float(out[0][1]) - meta["objective_at_step"]["0"]) < 2e-5
+    assert abs(float(out[500][1]) - meta["objective_at_step"]["500"]) < 2e-5
+    lam = R.second_moment_weight
+    assert lam(0) == 1e-6 and lam(250) == 1e-6 and lam(375) == 0.5 and lam(500) == 1.0 and lam(9999) == 1.0
+    mid = float(log["reconst_err"].mean() + lam(375) * log["second_moment_mse"].mean())
+    assert abs(mid - meta["objective_at_step"]["375"]) < 2e-5
+
+
+def test_gradients(run):
+    z, meta, c, P, out, taps = run
+    for tag, step in (("g0", 0), ("g500", 500)):
+        grads = out[step][3]
+        assert sum(g is not None for g in grads.values()) == meta[tag + ".n_params_with_grad"]
+        tot = np.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None))
+        assert abs(tot - meta[tag + ".grad_total_l2"]) < 2e-3 * meta[tag + ".grad_total_l2"]
+        for n, (amax, l2) in meta[tag + ".grad_absmax_l2"].items():
+            g = grads[n].numpy().reshape(-1)[:4096]
+            ref = z[f"{tag}.grad.{n}"]
+            # tolerance relative to the tensor's own max |grad| (reference fp32-vs-fp64 floor is 1e-3)
+            assert np.abs(g - ref).max() < 5e-3 * amax + 1e-12, (tag, n)
+
+
+def test_adam_two_steps(run):
+    z, meta, c, P, out, taps = run
+    noisy = torch.from_numpy(z["noisy"])
+    clean = torch.from_numpy(z["clean"])
+    Q = {k: v.detach().clone() for k, v in P.items()}
+    train = {k: v for k, v in Q.items() if k.startswith("audio_pc_wrapper")}
+    for v in train.values():
+        v.requires_grad_(True)
+    state = {}
+    for it, step in ((1, 500), (2, 501)):
+        _, obj, _ = R.nppc_step(noisy, clean, Q, c["K"], step, stft=(c["nfft"], c["hop"], c["nfft"]),
+                                g_rest=c["G_rest"], g_pc=c["G_pc"], sb_neighbors=c["sbn"])
+        if it == 2:
+            assert abs(float(obj) - meta["adam1.objective_next"]) < 5e-5
+        names = list(train)
+        gs = torch.autograd.grad(obj, [train[k] for k in names])
+        with torch.no_grad():
+            R.adam_step(train, dict(zip(names, gs)), state, it)
+        for k in z.files:
+            if k.startswith(f"adam{it}."):
+                n = k[len(f"adam{it}."):]
+                got = Q[n].detach().numpy().reshape(-1)[:4096]
+                w0 = W.make_weights({n: tuple(Q[n].shape)}, c["seed"])[n].reshape(-1)[:4096]
+                # the update is ~lr per element: compare the DELTA, not the weight
+                assert np.abs((got - w0) - (z[k] - w0)).max() < 0.05 * 1e-4 * it + 1e-9, (it, n)
+
+
+def test_standalone_gram_schmidt_and_dropband(golden_dir):
+    z, _ = load(golden_dir, "g0_tiny")
+    got = R.gram_schmidt_crm(torch.from_numpy(z["gs.in"])).numpy()
+    assert rel(got, z["gs.out"]) < 1e-5
+    x = torch.from_numpy(z["dropband.in"])
+    for g in (2, 3):
+        assert np.array_equal(R.band_drop(x, g).numpy(), z[f"dropband.out{g}"])
+    with pytest.raises(AssertionError):
+        R.band_drop(x[:2], 2)
+
+
+def test_explicit_lstm_recurrence_matches_fused():
+    torch.manual_seed(3)
+    spec = {k: v for k, v in W.fullsubnet_spec(num_freqs=9, sb_neighbors=2, sb_hidden=12).items()
+            if k.startswith("sb_model.sequence_model")}
+    P = {k: torch.from_numpy(v) for k, v in W.make_weights(spec, 5).items()}
+    x = torch.randn(7, 11, 8)
+    a = R.lstm2(x, P, "sb_model.sequence_model")
+    b = R.lstm2_steps(x, P, "sb_model.sequence_model")
+    assert (a - b).abs().max() < 1e-6
