@@ -1,0 +1,83 @@
+"""ctypes binding of libnppc_hip.so (include/nppc_hip.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  Importing this module
+without the built library, or calling an op without a HIP device, raises RuntimeError.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnppc_hip.so")
+
+PREC_BF16 = 0
+PREC_F32 = 1
+_ERR = {1: "bad argument", 2: "kernel launch failed", 3: "unsupported shape/configuration"}
+
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_f = ctypes.c_float
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python generative-audio_amd/build_ext.py` "
+                "(the NPPC-audio hot path has no non-HIP fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("nppc_audio (MI355X build) needs a HIP device: the hot path is HIP-only")
+
+
+def ptr(t):
+    if t is None:
+        return c_p(0)
+    assert t.is_cuda and t.is_contiguous(), "HIP ops take contiguous device tensors"
+    return c_p(t.data_ptr())
+
+
+def stream():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def dtype_of(prec):
+    return torch.bfloat16 if prec == PREC_BF16 else torch.float32
+
+
+P, I, L, F = c_p, c_i, c_l, c_f
+PL = ctypes.POINTER(c_l)
+PI = ctypes.POINTER(c_i)
+
+# argtypes of every entry point of include/nppc_hip.h (tests assert the two stay in sync)
+SIGS = {
+    "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
+    "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
+    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+}
+_bound = set()
+
+
+def call(name, *args):
+    """lib().<name>(*args); tensors -> device pointers; raises RuntimeError on a non-zero return."""
+    fn = getattr(lib(), name)
+    if name not in _bound:
+        fn.argtypes = SIGS[name]
+        fn.restype = c_i
+        _bound.add(name)
+    conv = [ptr(a) if (isinstance(a, torch.Tensor) or a is None) else a for a in args]
+    check(fn(*conv), name)

@@ -1,0 +1,57 @@
+"""Host side of the fused 2-layer LSTM kernels (csrc/lstm.hip)."""
+import ctypes
+
+import torch
+
+from . import _hip as H
+
+
+class PackedLSTM:
+    """Per-wave MFMA B-fragment packing of nn.LSTM(I,Hd,2) weights (+ summed biases)."""
+
+    def __init__(self, I, Hd, prec, device):
+        n1, n2, kx = ctypes.c_long(), ctypes.c_long(), ctypes.c_int()
+        H.call("nppc_lstm2_packed_elems", I, Hd, ctypes.byref(n1), ctypes.byref(n2), ctypes.byref(kx))
+        self.I, self.Hd, self.prec, self.kx = I, Hd, prec, kx.value
+        dt = H.dtype_of(prec)
+        self.wp1 = torch.empty(n1.value, dtype=dt, device=device)
+        self.wp2 = torch.empty(n2.value, dtype=dt, device=device)
+        self.bias1 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
+        self.bias2 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
+
+    def pack(self, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+        ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1)]
+        H.call("nppc_lstm2_pack_weights", self.prec, *ws, self.I, self.Hd, self.wp1, self.wp2, self.bias1,
+               self.bias2, H.stream())
+        return self
+
+
+def pick_mtile(n_seq, prec, train, n_cu=256):
+    """Rows per workgroup = 16*mtile: fill the CUs first, then grow the tile (weight reuse)."""
+    if prec == H.PREC_F32:
+        return 1
+    for mt in ((2,) if train else (3, 2)):
+        if (n_seq + 16 * mt - 1) // (16 * mt) >= n_cu * 2 // 3:
+            return mt
+    return 1
+
+
+def lstm2_forward(x_tm, packed, train, mtile=None):
+    """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1, g1, g2, c1, c2]) time-major."""
+    Tn, N, kx = x_tm.shape
+    assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
+    Hd = packed.Hd
+    dt, dev = x_tm.dtype, x_tm.device
+    out = {"h2": torch.empty(Tn, N, Hd, dtype=dt, device=dev)}
+    if train:
+        out["h1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
+        out["c1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
+        out["c2"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
+        out["g1"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
+        out["g2"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
+    if mtile is None:
+        mtile = pick_mtile(N, packed.prec, train)
+    H.call("nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
+           out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
+           H.stream())
+    return out

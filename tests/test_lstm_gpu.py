@@ -1,0 +1,91 @@
+"""GPU parity: fused 2-layer LSTM kernel (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nppc_ref as R
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(I, Hd, seed):
+    spec = {k: v for k, v in W.fullsubnet_spec(num_freqs=9, sb_neighbors=(I - 4) // 2, sb_hidden=Hd).items()
+            if k.startswith("sb_model.sequence_model")}
+    assert spec["sb_model.sequence_model.weight_ih_l0"][1] == I
+    return {k: torch.from_numpy(v) for k, v in W.make_weights(spec, seed).items()}
+
+
+def _run(I, Hd, N, Tn, prec, train, mtile, seed=0):
+    from nppc_audio import _hip as H
+    from nppc_audio.ops_lstm import PackedLSTM, lstm2_forward
+    P = _weights(I, Hd, seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Tn, I, generator=g)
+    ref = R.lstm2(x, P, "sb_model.sequence_model")                     # [N,Tn,H]
+    dev = torch.device("cuda")
+    pk = PackedLSTM(I, Hd, prec, dev)
+    pre = "sb_model.sequence_model."
+    pk.pack(*[P[pre + n].to(dev) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+                                             "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
+    xt = torch.zeros(Tn, N, pk.kx, dtype=H.dtype_of(prec), device=dev)
+    xt[:, :, :I] = x.permute(1, 0, 2).to(dev)
+    out = lstm2_forward(xt, pk, train, mtile)
+    torch.cuda.synchronize()
+    got = out["h2"].float().cpu().permute(1, 0, 2)
+    return got, ref, out, (x, P)
+
+
+@pytest.mark.parametrize("Hd,I", [(16, 10), (384, 34)])
+@pytest.mark.parametrize("train", [False, True])
+def test_lstm_fwd_f32_matches_oracle(Hd, I, train):
+    N, Tn = (37, 19) if Hd == 16 else (50, 23)
+    got, ref, out, (x, P) = _run(I, Hd, N, Tn, 1, train, 1)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5, err          # fp32 tolerance: exact-f32 MFMA, rcp/exp 1-ulp activations
+    if train:
+        # saved state: h1 and the post-activation gates/cell of both layers against the explicit recurrence
+        h1 = out["h1"].float().cpu().permute(1, 0, 2)
+        Pl0 = dict(P)
+        ref_h1 = _layer_out(x, P, 0)
+        assert (h1 - ref_h1).abs().max().item() < 2e-5
+        g2 = out["g2"].float().cpu()
+        assert torch.isfinite(g2).all() and g2[..., 0].min() >= 0 and g2[..., 0].max() <= 1   # i
+        assert g2[..., 1].abs().max() <= 1 + 1e-6                                            # g (tanh)
+        c2 = out["c2"].float().cpu().permute(1, 0, 2)
+        o2 = g2[..., 3].permute(1, 0, 2)
+        assert (o2 * torch.tanh(c2) - got).abs().max().item() < 2e-5                         # h = o*tanh(c)
+
+
+def _layer_out(x, P, layer):
+    pre = "sb_model.sequence_model."
+    Hd = P[pre + "weight_hh_l0"].shape[1]
+    wi, wh = P[pre + f"weight_ih_l{layer}"], P[pre + f"weight_hh_l{layer}"]
+    b = P[pre + f"bias_ih_l{layer}"] + P[pre + f"bias_hh_l{layer}"]
+    h = x.new_zeros(x.shape[0], Hd)
+    c = x.new_zeros(x.shape[0], Hd)
+    outs = []
+    for t in range(x.shape[1]):
+        g = x[:, t] @ wi.t() + h @ wh.t() + b
+        i, f, gg, o = g.split(Hd, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+@pytest.mark.parametrize("Hd,I,mtile", [(16, 10, 1), (16, 10, 2), (384, 34, 1), (384, 34, 2), (384, 34, 3)])
+def test_lstm_fwd_bf16_matches_oracle(Hd, I, mtile):
+    N, Tn = (37, 19) if Hd == 16 else (70, 40)
+    got, ref, _, _ = _run(I, Hd, N, Tn, 0, False, mtile)
+    err = (got - ref).abs().max().item()
+    # bf16 operands (2^-9 relative rounding of x, h, W), fp32 accumulate and cell state
+    assert err < 3e-2, err
+
+
+def test_lstm_fwd_bf16_train_saves_consistent_state():
+    got, ref, out, _ = _run(34, 384, 40, 12, 0, True, 2)
+    assert (got - ref).abs().max().item() < 3e-2
+    c2 = out["c2"].float().cpu().permute(1, 0, 2)
+    o2 = out["g2"].float().cpu()[..., 3].permute(1, 0, 2)
+    assert (o2 * torch.tanh(c2) - got).abs().max().item() < 2e-2
