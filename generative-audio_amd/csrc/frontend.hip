@@ -1,0 +1,219 @@
+// Signal front end of the NPPC train step: batched STFT, cIRM build/compress (+drop-band),
+// cIRM decompress + conj-mask application, drop-band gather.  All HBM-bound, fp32.
+// Reference call sites (under /root/reference):
+//   STFT        utils.py:107-147 (torch.stft centre/reflect, periodic hann), nppc_audio/trainer.py:349-355
+//   cIRM build  FullSubNet_plus/speech_enhance/audio_zen/acoustics/mask.py:24-54, trainer.py:357-362
+//   decompress  mask.py:57-60;  mask application utils.py:241-249 -> :75-79 (real/imag swapped: conj(mask)*noisy)
+//   drop_band   audio_zen/acoustics/feature.py:254-285
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- STFT
+// One workgroup = FR consecutive frames of one clip.  Radix-2 DIT FFT in LDS (complex N points,
+// imaginary input 0), twiddles/window generated in fp64 -> fp32 once per workgroup.
+// Output layout [B][F][T] (F = N/2+1), written with the FR frames of a bin contiguous.
+constexpr int STFT_FR = 8;
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wave, float* __restrict__ out_re,
+                                                   float* __restrict__ out_im, float* __restrict__ out_mag, int L,
+                                                   int hop, int T) {
+  constexpr int N = 1 << LOGN;
+  constexpr int F = N / 2 + 1;
+  __shared__ float2 buf[STFT_FR][N + 1];
+  __shared__ float2 tw[N / 2];
+  __shared__ float win[N];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * STFT_FR;
+  for (int i = tid; i < N / 2; i += 256) {
+    double s, c;
+    sincospi(-2.0 * i / N, &s, &c);
+    tw[i] = make_float2((float)c, (float)s);
+  }
+  for (int i = tid; i < N; i += 256) win[i] = (float)(0.5 - 0.5 * cospi(2.0 * i / N));
+  __syncthreads();
+  const float* wv = wave + (size_t)b * L;
+  // load, window, bit-reverse
+  for (int e = tid; e < STFT_FR * N; e += 256) {
+    const int j = e / N, n = e % N;
+    const int t = t0 + j;
+    float v = 0.f;
+    if (t < T) {
+      int sidx = t * hop + n - N / 2;
+      if (sidx < 0) sidx = -sidx;
+      if (sidx >= L) sidx = 2 * (L - 1) - sidx;
+      v = wv[sidx] * win[n];
+    }
+    const int r = __brev((unsigned)n) >> (32 - LOGN);
+    buf[j][r] = make_float2(v, 0.f);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < LOGN; ++s) {
+    const int half = 1 << s;
+    for (int e = tid; e < STFT_FR * (N / 2); e += 256) {
+      const int j = e / (N / 2), k = e % (N / 2);
+      const int grp = k >> s, pos = k & (half - 1);
+      const int i0 = (grp << (s + 1)) + pos, i1 = i0 + half;
+      const float2 w = tw[pos << (LOGN - 1 - s)];
+      const float2 a = buf[j][i0], c = buf[j][i1];
+      const float xr = c.x * w.x - c.y * w.y, xi = c.x * w.y + c.y * w.x;
+      buf[j][i0] = make_float2(a.x + xr, a.y + xi);
+      buf[j][i1] = make_float2(a.x - xr, a.y - xi);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < F * STFT_FR; e += 256) {
+    const int f = e / STFT_FR, j = e % STFT_FR;
+    const int t = t0 + j;
+    if (t < T) {
+      const float2 v = buf[j][f];
+      const size_t o = ((size_t)b * F + f) * T + t;
+      out_re[o] = v.x;
+      out_im[o] = v.y;
+      if (out_mag) out_mag[o] = sqrtf(v.x * v.x + v.y * v.y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- drop-band index math
+// drop_band(x[B,C,F,T], G): F trimmed to F - F%G, output batch = groups concatenated
+// (group g = samples g, g+G, ...), sample of group g keeps bins g, g+G, ...
+__device__ __forceinline__ void dropband_src(int bo, int fo, int B, int G, int* b_src, int* f_src) {
+  if (G <= 1) { *b_src = bo; *f_src = fo; return; }
+  int g = 0, start = 0;
+  for (; g < G; ++g) {
+    const int cnt = (B - g + G - 1) / G;
+    if (bo < start + cnt) break;
+    start += cnt;
+  }
+  *b_src = g + (bo - start) * G;
+  *f_src = g + fo * G;
+}
+
+// out[bo][c][fo][t] = in[b_src][c][f_src][t]
+__global__ void dropband_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int F, int T, int G,
+                                int Fo) {
+  const size_t total = (size_t)B * C * Fo * T;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = e % T;
+    size_t r = e / T;
+    const int fo = r % Fo; r /= Fo;
+    const int c = r % C;
+    const int bo = (int)(r / C);
+    int bs, fs;
+    dropband_src(bo, fo, B, G, &bs, &fs);
+    out[e] = in[(((size_t)bs * C + c) * F + fs) * T + t];
+  }
+}
+
+__device__ __forceinline__ float compress_cirm(float m) {
+  m = m <= -100.f ? -100.f : m;
+  const float e = expf(-0.1f * m);
+  return 10.f * (1.f - e) / (1.f + e);
+}
+
+// gt[bo][{0,1}][fo][t] = compress(cIRM(noisy, clean))[b_src][f_src][t]
+__global__ void cirm_build_kernel(const float* __restrict__ nr, const float* __restrict__ ni, const float* __restrict__ cr,
+                                  const float* __restrict__ ci, float* __restrict__ out, int B, int F, int T, int G, int Fo,
+                                  float eps) {
+  const size_t total = (size_t)B * Fo * T;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int t = e % T;
+    size_t r = e / T;
+    const int fo = r % Fo;
+    const int bo = (int)(r / Fo);
+    int bs, fs;
+    dropband_src(bo, fo, B, G, &bs, &fs);
+    const size_t i = ((size_t)bs * F + fs) * T + t;
+    const float a = nr[i], b = ni[i], c = cr[i], d = ci[i];
+    const float den = a * a + b * b + eps;
+    const float mr = (a * c + b * d) / den;
+    const float mi = (a * d - b * c) / den;
+    const size_t o = (((size_t)bo * 2) * Fo + fo) * T + t;
+    out[o] = compress_cirm(mr);
+    out[o + (size_t)Fo * T] = compress_cirm(mi);
+  }
+}
+
+__device__ __forceinline__ float decompress_cirm(float m) {
+  m = fminf(fmaxf(m, -9.9f), 9.9f);
+  return -10.f * logf((10.f - m) / (10.f + m));
+}
+
+// crm [B][2][F][T] compressed -> dec [B][F][T][2] (optional), enhanced mag/re/im [B][F][T]
+__global__ void decompress_apply_kernel(const float* __restrict__ crm, const float* __restrict__ nr,
+                                        const float* __restrict__ ni, float* __restrict__ dec, float* __restrict__ emag,
+                                        float* __restrict__ ere, float* __restrict__ eim, int B, int F, int T) {
+  const size_t FT = (size_t)F * T, total = (size_t)B * FT;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = e / FT, r = e % FT;
+    const float mr = decompress_cirm(crm[(b * 2) * FT + r]);
+    const float mi = decompress_cirm(crm[(b * 2 + 1) * FT + r]);
+    const float a = nr[e], c = ni[e];
+    const float xr = mr * a + mi * c;   // conj(mask) * noisy: the reference's swapped call (utils.py:241-249)
+    const float xi = mr * c - mi * a;
+    if (dec) { dec[2 * e] = mr; dec[2 * e + 1] = mi; }
+    ere[e] = xr;
+    eim[e] = xi;
+    emag[e] = sqrtf(xr * xr + xi * xi);
+  }
+}
+
+static int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int nppc_stft(const float* wave, float* re, float* im, float* mag, int B, int L, int nfft, int hop, void* stream) {
+  if (!wave || !re || !im || B <= 0 || L <= nfft / 2 || hop <= 0) return NPPC_EBADARG;
+  const int T = 1 + L / hop;
+  dim3 grid(ceil_div(T, STFT_FR), B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (nfft) {
+    case 64: hipLaunchKernelGGL(stft_kernel<6>, grid, dim3(256), 0, s, wave, re, im, mag, L, hop, T); break;
+    case 128: hipLaunchKernelGGL(stft_kernel<7>, grid, dim3(256), 0, s, wave, re, im, mag, L, hop, T); break;
+    case 256: hipLaunchKernelGGL(stft_kernel<8>, grid, dim3(256), 0, s, wave, re, im, mag, L, hop, T); break;
+    case 512: hipLaunchKernelGGL(stft_kernel<9>, grid, dim3(256), 0, s, wave, re, im, mag, L, hop, T); break;
+    default: return NPPC_EUNSUPPORTED;
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_dropband(const float* in, float* out, int B, int C, int F, int T, int G, void* stream) {
+  if (!in || !out || B <= 0 || G < 1) return NPPC_EBADARG;
+  const int Fo = G <= 1 ? F : (F - F % G) / G;
+  hipLaunchKernelGGL(dropband_kernel, dim3(ew_grid((size_t)B * C * Fo * T)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     B, C, F, T, G, Fo);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_cirm_build_compress(const float* nr, const float* ni, const float* cr, const float* ci, float* out, int B, int F,
+                             int T, int G, float eps, void* stream) {
+  if (!nr || !ni || !cr || !ci || !out || B <= 0 || G < 1) return NPPC_EBADARG;
+  const int Fo = G <= 1 ? F : (F - F % G) / G;
+  hipLaunchKernelGGL(cirm_build_kernel, dim3(ew_grid((size_t)B * Fo * T)), dim3(256), 0, (hipStream_t)stream, nr, ni, cr,
+                     ci, out, B, F, T, G, Fo, eps);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_cirm_decompress_apply_conj(const float* crm, const float* nr, const float* ni, float* dec, float* emag,
+                                    float* ere, float* eim, int B, int F, int T, void* stream) {
+  if (!crm || !nr || !ni || !emag || !ere || !eim || B <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(decompress_apply_kernel, dim3(ew_grid((size_t)B * F * T)), dim3(256), 0, (hipStream_t)stream, crm, nr,
+                     ni, dec, emag, ere, eim, B, F, T);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,344 @@
+// Full-band sequence model: 8 x TCNBlock + Linear + ReLU on time-major activations.
+// Reference: audio_zen/model/module/causal_conv.py:67-108 (TCNBlock: conv1x1, PReLU, GroupNorm(1,512,eps=1e-8),
+// depthwise dilated conv k=3, PReLU, GroupNorm, sconv, skip), sequence_model.py:47-58,106-112.
+//
+// Layout: activations are [B][Tp][ld] (frames x channels, channels contiguous, Tp = T' rounded up to 128,
+// ld = channels rounded up to 64, padding zero) so every 1x1 conv / Linear is one row-major NT GEMM
+//   Y[R][N] = X[R][K] * W[N][K]^T,  R = B*Tp
+// on bf16 (or exact-f32) MFMA 16x16 tiles, with bias / PReLU / GroupNorm statistics / residual fused in the epilogue.
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+enum { EPI_PLAIN = 0, EPI_PRELU_STATS = 1, EPI_RESIDUAL = 2, EPI_RELU = 3 };
+
+struct GemmArgs {
+  const void* A; long lda; long strideA;   // [R][lda]   (strides in elements, per batch z)
+  const void* B; long ldb; long strideB;   // [N][ldb]
+  void* C; long ldc; long strideC;         // [R][ldc]
+  const float* bias; long strideBias;      // [N] or null
+  const void* res; long ldres; long strideRes;  // residual [R][ldres] (EPI_RESIDUAL)
+  const float* slope; long strideSlope;    // PReLU slope (1 value)
+  double* stats; long strideStats;         // [R/Tp][2] (sum, sumsq) (EPI_PRELU_STATS)
+  int R, N, K;                             // R % 128 == 0, N % 64 == 0, K % 32 == 0
+  int Tp, Tv;                              // rows with (row % Tp) >= Tv are padding: forced to zero
+  int Nv;                                  // columns >= Nv are padding: forced to zero
+  int relu_in;                             // apply ReLU to A on load (TCN trailing nn.ReLU before the Linear)
+};
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type relu_frag(typename Frag<T>::type f);
+template <> __device__ __forceinline__ bf16x8 relu_frag<bf16_t>(bf16x8 f) {
+  u32x4 v = __builtin_bit_cast(u32x4, f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned x = v[i];
+    if (x & 0x8000u) x &= 0xffff0000u;
+    if (x & 0x80000000u) x &= 0x0000ffffu;
+    v[i] = x;
+  }
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <> __device__ __forceinline__ f32x8 relu_frag<float>(f32x8 f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f);
+  return f;
+}
+
+// 256 threads = 4 waves stacked over rows; wave tile 32 x 64, block tile 128 x 64.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+  typedef typename Frag<T>::type frag;
+  const int z = blockIdx.z;
+  const T* A = reinterpret_cast<const T*>(g.A) + (size_t)z * g.strideA;
+  const T* B = reinterpret_cast<const T*>(g.B) + (size_t)z * g.strideB;
+  T* C = reinterpret_cast<T*>(g.C) + (size_t)z * g.strideC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * 128 + wave * 32, c0 = blockIdx.y * 64;
+  const T* ap = A + (size_t)(r0 + n) * g.lda + 8 * q;
+  const T* bp = B + (size_t)(c0 + n) * g.ldb + 8 * q;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = g.K / 32;
+  frag a0[2], b0[4], a1[2], b1[4];
+  auto ld = [&](frag(&a)[2], frag(&b)[4], int kk) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi] = load_frag<T>(ap + (size_t)16 * mi * g.lda + 32 * kk);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b[ni] = load_frag<T>(bp + (size_t)16 * ni * g.ldb + 32 * kk);
+  };
+  auto mm = [&](frag(&a)[2], frag(&b)[4]) {
+    if (g.relu_in) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = relu_frag<T>(a[mi]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mma16(a[mi], b[ni], acc[mi][ni]);
+  };
+  ld(a0, b0, 0);
+  int kk = 0;
+#pragma unroll 1
+  for (; kk + 2 < nk; kk += 2) {
+    ld(a1, b1, kk + 1);
+    mm(a0, b0);
+    ld(a0, b0, kk + 2);
+    mm(a1, b1);
+  }
+  if (kk + 1 < nk) {
+    ld(a1, b1, kk + 1);
+    mm(a0, b0);
+    mm(a1, b1);
+  } else {
+    mm(a0, b0);
+  }
+
+  // ---- epilogue: element (row r0+16mi+4q+j, col c0+16ni+n)
+  const float* bias = g.bias ? g.bias + (size_t)z * g.strideBias : nullptr;
+  float slope = 0.f;
+  if (EPI == EPI_PRELU_STATS) slope = g.slope[(size_t)z * g.strideSlope];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = c0 + 16 * ni + n;
+    const bool cvalid = col < g.Nv;
+    const float bv = (bias && cvalid) ? bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = r0 + 16 * mi + 4 * q + j;
+        const bool valid = cvalid && (row % g.Tp) < g.Tv;
+        float v = acc[mi][ni][j] + bv;
+        if (EPI == EPI_PRELU_STATS) v = v > 0.f ? v : slope * v;
+        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI == EPI_RESIDUAL) {
+          const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+          v += to_f32<T>(res[(size_t)row * g.ldres + col]);
+        }
+        if (!valid) v = 0.f;
+        const T o = from_f32<T>(v);
+        C[(size_t)row * g.ldc + col] = o;
+        if (EPI == EPI_PRELU_STATS) {
+          const float vo = to_f32<T>(o);   // statistics of the STORED (rounded) activations
+          s1 += vo;
+          s2 += vo * vo;
+        }
+      }
+  }
+  if (EPI == EPI_PRELU_STATS) {
+    double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+    if (lane == 0) {
+      double* st = g.stats + (size_t)z * g.strideStats + (size_t)(r0 / g.Tp) * 2;
+      atomicAdd(st, d1);
+      atomicAdd(st + 1, d2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- depthwise stage
+// in  = y1 [B][Tp][ld] (post-PReLU1), GroupNorm-1 statistics (sum, sumsq over the C*Tv valid elements)
+// z   = GN1(y1) on valid frames, 0 outside (conv zero padding)
+// out = PReLU2( bias[c] + sum_k w[c][k] * z[t + (k-1)*dil][c] )   (+ GroupNorm-2 statistics of out)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                     const double* __restrict__ st1, double* __restrict__ st2,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ wd, const float* __restrict__ bd,
+                                                     const float* __restrict__ slope2, int Cc, int ld, int Tp, int Tv, int dil,
+                                                     float eps, long strideAct, long strideSt, long strideP) {
+  const int z = blockIdx.z, b = blockIdx.y;
+  in += (size_t)z * strideAct;
+  out += (size_t)z * strideAct;
+  st1 += (size_t)z * strideSt;
+  st2 += (size_t)z * strideSt;
+  gamma += (size_t)z * strideP; beta += (size_t)z * strideP; bd += (size_t)z * strideP; wd += (size_t)z * strideP;
+  const float a2 = slope2[(size_t)z * strideP];
+  const double cnt = (double)Cc * Tv;
+  const double m = st1[b * 2] / cnt;
+  const double var = st1[b * 2 + 1] / cnt - m * m;
+  const float mean = (float)m, rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  const int cpr = Cc / 8;        // 8-channel chunks per frame; host guarantees cpr <= 256
+  const int rpb = 256 / cpr;     // frames per block
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  const int t = blockIdx.x * rpb + tl;
+  float s1 = 0.f, s2 = 0.f;
+  if (tl < rpb && t < Tp) {
+    float o[8];
+    if (t < Tv) {
+      float g8[8], be8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        g8[i] = gamma[c8 + i] * rstd;
+        be8[i] = beta[c8 + i] - mean * g8[i];
+        o[i] = bd[c8 + i];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ts = t + (k - 1) * dil;
+        if (ts >= 0 && ts < Tv) {
+          const T* p = in + ((size_t)b * Tp + ts) * ld + c8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += wd[(c8 + i) * 3 + k] * (to_f32<T>(p[i]) * g8[i] + be8[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = o[i] > 0.f ? o[i] : a2 * o[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    }
+    T* po = out + ((size_t)b * Tp + t) * ld + c8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const T ov = from_f32<T>(o[i]);
+      po[i] = ov;
+      const float vf = to_f32<T>(ov);
+      s1 += vf;
+      s2 += vf * vf;
+    }
+  }
+  const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(st2 + b * 2, d1);
+    atomicAdd(st2 + b * 2 + 1, d2);
+  }
+}
+
+// y = GN(x) = (x - mean) * rstd * gamma + beta on valid frames (padding stays 0)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                       const double* __restrict__ st, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int Cc, int ld, int Tp, int Tv,
+                                                       float eps, long strideAct, long strideSt, long strideP) {
+  const int z = blockIdx.z, b = blockIdx.y;
+  in += (size_t)z * strideAct;
+  out += (size_t)z * strideAct;
+  st += (size_t)z * strideSt;
+  gamma += (size_t)z * strideP; beta += (size_t)z * strideP;
+  const double cnt = (double)Cc * Tv;
+  const double m = st[b * 2] / cnt;
+  const double var = st[b * 2 + 1] / cnt - m * m;
+  const float mean = (float)m, rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  const int cpr = Cc / 8;
+  const long total = (long)Tv * cpr;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int t = (int)(e / cpr), c8 = (int)(e % cpr) * 8;
+    const T* p = in + ((size_t)b * Tp + t) * ld + c8;
+    T* po = out + ((size_t)b * Tp + t) * ld + c8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float gsc = gamma[c8 + i] * rstd;
+      po[i] = from_f32<T>((to_f32<T>(p[i]) - mean) * gsc + beta[c8 + i]);
+    }
+  }
+}
+
+// dst[n][k] (ld = ldd, zero padded) = src[n][k] * (colscale ? colscale[k] : 1), n < N, k < K;  T = bf16 / f32
+template <typename T>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int K, int Npad, int ldd,
+                                   int transpose) {
+  const long total = (long)Npad * ldd;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int nn = (int)(e / ldd), k = (int)(e % ldd);
+    float v = 0.f;
+    if (!transpose) {
+      if (nn < N && k < K) v = src[(size_t)nn * K + k];
+    } else {  // dst[n][k] = src[k][n], src is [K][N]
+      if (nn < N && k < K) v = src[(size_t)k * N + nn];
+    }
+    dst[e] = from_f32<T>(v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                 long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
+                 long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
+                 int batch, void* stream) {
+  if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0 || batch <= 0) return NPPC_EBADARG;
+  if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
+  if (epi == EPI_PRELU_STATS && (!slope || !stats)) return NPPC_EBADARG;
+  if (epi == EPI_RESIDUAL && !res) return NPPC_EBADARG;
+  GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
+             R, N, K, Tp, Tv, Nv, relu_in};
+  dim3 grid(R / 128, N / 64, batch);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(TT, E) hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), grid, dim3(256), 0, s, g)
+  if (prec == NPPC_PREC_BF16) {
+    switch (epi) {
+      case EPI_PLAIN: LAUNCH(bf16_t, EPI_PLAIN); break;
+      case EPI_PRELU_STATS: LAUNCH(bf16_t, EPI_PRELU_STATS); break;
+      case EPI_RESIDUAL: LAUNCH(bf16_t, EPI_RESIDUAL); break;
+      case EPI_RELU: LAUNCH(bf16_t, EPI_RELU); break;
+      default: return NPPC_EBADARG;
+    }
+  } else if (prec == NPPC_PREC_F32) {
+    switch (epi) {
+      case EPI_PLAIN: LAUNCH(float, EPI_PLAIN); break;
+      case EPI_PRELU_STATS: LAUNCH(float, EPI_PRELU_STATS); break;
+      case EPI_RESIDUAL: LAUNCH(float, EPI_RESIDUAL); break;
+      case EPI_RELU: LAUNCH(float, EPI_RELU); break;
+      default: return NPPC_EBADARG;
+    }
+  } else {
+    return NPPC_EBADARG;
+  }
+#undef LAUNCH
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
+                    const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
+                    int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
+  if (!in || !out || !st1 || !st2 || Cc % 8 || Cc / 8 > 256) return NPPC_EBADARG;
+  const int cpr = Cc / 8, rpb = 256 / cpr;
+  dim3 grid(ceil_div(Tp, rpb), B, batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, st1, st2, gamma, beta,
+                       wd, bd, slope2, Cc, ld, Tp, Tv, dil, eps, sAct, sSt, sP);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, st1, st2, gamma, beta, wd,
+                       bd, slope2, Cc, ld, Tp, Tv, dil, eps, sAct, sSt, sP);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_tcn_gn_apply(int prec, const void* in, void* out, const double* st, const float* gamma, const float* beta, int B,
+                      int Cc, int ld, int Tp, int Tv, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
+  if (!in || !out || !st || Cc % 8) return NPPC_EBADARG;
+  dim3 grid(ceil_div((long)Tv * (Cc / 8), 256), B, batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, st, gamma, beta, Cc,
+                       ld, Tp, Tv, eps, sAct, sSt, sP);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, st, gamma, beta, Cc, ld,
+                       Tp, Tv, eps, sAct, sSt, sP);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream) {
+  if (!src || !dst || N > Npad || K > ldd) return NPPC_EBADARG;
+  const long total = (long)Npad * ldd;
+  const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, N, K, Npad, ldd, transpose);
+  else
+    hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, N, K, Npad, ldd, transpose);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

@@ -68,6 +68,20 @@ SIGS = {
     "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
     "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
     "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "nppc_stft": [P, P, P, P, I, I, I, I, P],
+    "nppc_dropband": [P, P, I, I, I, I, I, P],
+    "nppc_cirm_build_compress": [P, P, P, P, P, I, I, I, I, F, P],
+    "nppc_cirm_decompress_apply_conj": [P, P, P, P, P, P, P, I, I, I, P],
+    "nppc_rowsum": [P, P, L, I, P],
+    "nppc_tsse_fwd": [P, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
+    "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, P],
+    "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],
+    "nppc_subband_mean": [I, P, I, P, I, L, P, P, I, I, I, I, I, P],
+    "nppc_subband_stage": [I, P, I, P, I, L, P, P, I, I, I, I, I, I, I, P],
+    "nppc_sb_head": [I, P, P, P, P, L, I, I, I, I, I, P],
 }
 _bound = set()
 

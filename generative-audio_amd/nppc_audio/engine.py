@@ -1,0 +1,257 @@
+"""Launch sequences of the FullSubNet+-shaped nets on the HIP kernels (no torch compute ops).
+
+`FSNEngine` owns the packed weights, the time-major activation buffers and the launch order for
+one net (the frozen restorer: 3 input maps; the direction net: 6 maps, 2K outputs).  It mirrors
+FullSubNet_Plus.forward (FullSubNet_plus/.../fullsubnet_plus.py:143-230) and
+MultiDirectionFullSubNet_Plus.forward (nppc_audio/networks.py:63-163) stage by stage.
+"""
+import numpy as np
+import torch
+
+from . import _hip as H
+from .ops_lstm import PackedLSTM, lstm2_forward, pick_mtile
+
+TCN_HIDDEN = 512
+TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
+BRANCHES = ("", "_real", "_imag")   # channel_attention{,_real,_imag} / fb_model{,_real,_imag}
+EPI_PLAIN, EPI_PRELU_STATS, EPI_RESIDUAL, EPI_RELU = 0, 1, 2, 3
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class FlatParams:
+    """All parameters of a module re-homed into ONE fp32 device buffer (named_parameters order).
+
+    The three full-band branches are identical sub-trees laid out back to back, so any parameter of
+    branch z sits at a constant element stride from branch 0: kernels batch the branches over
+    blockIdx.z with that single stride.  Parameters stay individual nn.Parameters (views), so
+    state_dict()/optimizers see the reference names and shapes.
+    """
+
+    def __init__(self, module, device):
+        named = list(module.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.grad = None
+        self.off = {}
+        o = 0
+        for n, p in named:
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[o:o + k].view(p.shape)
+            self.off[n] = (o, tuple(p.shape))
+            o += k
+        self.named = named
+
+    def view(self, name):
+        o, shp = self.off[name]
+        return self.flat[o:o + int(np.prod(shp))].view(shp)
+
+    def gview(self, name):
+        o, shp = self.off[name]
+        return self.grad[o:o + int(np.prod(shp))].view(shp)
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.flat)
+        return self.grad
+
+    def branch_stride(self):
+        a = self.off["fb_model.fc_output_layer.weight"][0]
+        b = self.off["fb_model_real.fc_output_layer.weight"][0]
+        c = self.off["fb_model_imag.fc_output_layer.weight"][0]
+        assert b - a == c - b > 0
+        a2 = self.off["fb_model.sequence_model.0.conv1x1.weight"][0]
+        b2 = self.off["fb_model_real.sequence_model.0.conv1x1.weight"][0]
+        assert b2 - a2 == b - a
+        return b - a
+
+
+def unfold_multiplicity(F, nb):
+    """mult[f] = number of (bin, tap) pairs whose reflected source bin is f (sum of the unfolded block)."""
+    m = np.zeros(F, np.float32)
+    for f in range(F):
+        for j in range(-nb, nb + 1):
+            i = f + j
+            if i < 0:
+                i = -i
+            if i >= F:
+                i = 2 * (F - 1) - i
+            m[i] += 1
+    return m
+
+
+class FSNEngine:
+    def __init__(self, flat, *, num_freqs, n_maps, out_size, sb_neighbors, look_ahead, sb_hidden, groups, kersize,
+                 prec, trainable):
+        self.fp = flat
+        self.F, self.nm, self.O = num_freqs, n_maps, out_size
+        self.nb, self.la, self.Hd, self.G = sb_neighbors, look_ahead, sb_hidden, groups
+        self.ks = tuple(kersize)
+        self.prec = prec
+        self.dt = H.dtype_of(prec)
+        self.trainable = trainable
+        self.C = n_maps * num_freqs
+        self.ldC = rup(self.C, 64)
+        self.ldF = rup(num_freqs, 64)
+        self.KC = rup(self.C, 32)
+        self.dev = flat.flat.device
+        self.I = 2 * sb_neighbors + 1 + 3
+        self.sP = flat.branch_stride()
+        self.packed_version = None
+        self.bufs = {}
+        self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
+        self.KX = self.lstm.kx
+        self.mult = torch.from_numpy(unfold_multiplicity(self.F, self.nb)).to(self.dev)
+        C, ldC, ldF = self.C, self.ldC, self.ldF
+        self.W1p = torch.zeros(8, 3, TCN_HIDDEN, ldC, dtype=self.dt, device=self.dev)
+        self.W2p = torch.zeros(8, 3, ldC, TCN_HIDDEN, dtype=self.dt, device=self.dev)
+        self.Wfcp = torch.zeros(3, ldF, ldC, dtype=self.dt, device=self.dev)
+        self.Opad = rup(self.O, 16)
+        self.Whp = torch.zeros(self.Opad, self.Hd, dtype=self.dt, device=self.dev)
+
+    # ------------------------------------------------------------------ weights
+    def p(self, name):
+        return self.fp.view(name)
+
+    def pack_weights(self, force=False):
+        ver = self.fp.flat._version
+        if not force and self.packed_version == ver:
+            return
+        s = H.stream()
+        C, ldC, ldF = self.C, self.ldC, self.ldF
+        for z, br in enumerate(BRANCHES):
+            for i in range(8):
+                pre = f"fb_model{br}.sequence_model.{i}"
+                H.call("nppc_pack_matrix", self.prec, self.p(pre + ".conv1x1.weight"), self.W1p[i, z], TCN_HIDDEN, C,
+                       TCN_HIDDEN, ldC, 0, s)
+                H.call("nppc_pack_matrix", self.prec, self.p(pre + ".sconv.weight"), self.W2p[i, z], C, TCN_HIDDEN, ldC,
+                       TCN_HIDDEN, 0, s)
+            H.call("nppc_pack_matrix", self.prec, self.p(f"fb_model{br}.fc_output_layer.weight"), self.Wfcp[z], self.F, C,
+                   ldF, ldC, 0, s)
+        H.call("nppc_pack_matrix", self.prec, self.p("sb_model.fc_output_layer.weight"), self.Whp, self.O, self.Hd,
+               self.Opad, self.Hd, 0, s)
+        q = "sb_model.sequence_model."
+        self.lstm.pack(*[self.p(q + n) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
+                                                  "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
+        self.packed_version = self.fp.flat._version
+
+    # ------------------------------------------------------------------ buffers
+    def _buffers(self, B, T, train):
+        key = (B, T, train)
+        if key in self.bufs:
+            return self.bufs[key]
+        dev, dt = self.dev, self.dt
+        Tv = T + self.la
+        Tp = rup(Tv, 128)
+        nblk = 8 if train else 1
+        d = dict(B=B, T=T, Tv=Tv, Tp=Tp)
+        d["rs"] = torch.empty(3 * self.nm, B, self.F, dtype=torch.float64, device=dev)
+        d["scale"] = torch.empty(3, self.nm, B, self.F, dtype=torch.float32, device=dev)
+        d["X"] = torch.zeros(9 if train else 3, 3, B, Tp, self.ldC, dtype=dt, device=dev)   # X[0] = TCN input (kept)
+        d["y1"] = torch.zeros(nblk, 3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
+        d["y2"] = torch.zeros(nblk, 3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
+        d["a2"] = torch.zeros(3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
+        d["stats"] = torch.zeros(8, 2, 3, B, 2, dtype=torch.float64, device=dev)
+        d["fb"] = torch.zeros(3, B, Tp, self.ldF, dtype=dt, device=dev)
+        if self.nm == 2:
+            d["rawmag"] = torch.zeros(B, Tp, self.ldF, dtype=dt, device=dev)
+        d["sbscale"] = torch.empty(B, dtype=torch.float32, device=dev)
+        G = self.G if B > 1 else 1
+        Fo = self.F if G <= 1 else (self.F - self.F % G) // G
+        d["G"], d["Fo"], d["Nseq"] = G, Fo, B * Fo
+        d["x_tm"] = torch.empty(Tv, B * Fo, self.KX, dtype=dt, device=dev)
+        if train:
+            d["tsse_saved"] = {k: torch.empty(3, self.nm, B, *shp, dtype=torch.float32, device=dev)
+                               for k, shp in (("ns", ()), ("pre", (self.F, 3)), ("sq", (self.F,)),
+                                              ("h1", (self.F // 2,)), ("sg", (self.F,)))}
+        self.bufs[key] = d
+        return d
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, maps, train=False, mtile=None):
+        """maps: 3*n_maps tensors [B,1,F,T] fp32 ordered (mag, real, imag)[, (enh mag, real, imag)].
+        Returns the net output [B', O, F', T] fp32 (B' in drop-band order) and keeps what backward needs."""
+        H.require_gpu()
+        assert len(maps) == 3 * self.nm
+        for m in maps:
+            assert m.dim() == 4, "inputs are [B, 1, F, T]"      # fullsubnet_plus.py:157
+            assert m.shape[1] == 1 and m.shape[2] == self.F
+        B, _, F, T = maps[0].shape
+        if B > 1:
+            assert B > self.G, f"Batch size = {B}, num_groups = {self.G}."   # feature.py:263
+        self.pack_weights()
+        d = self._buffers(B, T, train)
+        s = H.stream()
+        Tv, Tp, prec = d["Tv"], d["Tp"], self.prec
+        C, ldC, ldF, sP = self.C, self.ldC, self.ldF, self.sP
+        R = B * Tp
+        maps = [m.contiguous().float() for m in maps]
+        sv = d.get("tsse_saved")
+        # 1-3: laplace norm + TSSE attention scale, transposed into the TCN input
+        for z, br in enumerate(BRANCHES):
+            att = f"channel_attention{br}."
+            for m in range(self.nm):
+                x = maps[m * 3 + z]
+                rs = d["rs"][m * 3 + z]
+                H.call("nppc_rowsum", x, rs, B * F, T, s)
+                sav = [sv[k][z, m] if sv else None for k in ("ns", "pre", "sq", "h1", "sg")]
+                H.call("nppc_tsse_fwd", x, rs,
+                       self.p(att + "smallConv1d.0.weight"), self.p(att + "smallConv1d.0.bias"),
+                       self.p(att + "middleConv1d.0.weight"), self.p(att + "middleConv1d.0.bias"),
+                       self.p(att + "largeConv1d.0.weight"), self.p(att + "largeConv1d.0.bias"),
+                       self.ks[0], self.ks[1], self.ks[2],
+                       self.p(att + "feature_concate_fc.weight"), self.p(att + "feature_concate_fc.bias"),
+                       self.p(att + "fc1.weight"), self.p(att + "fc1.bias"), self.p(att + "fc2.weight"),
+                       self.p(att + "fc2.bias"), d["scale"][z, m], *sav, B, F, T, self.la, s)
+                H.call("nppc_scale_transpose", prec, x, d["scale"][z, m], d["X"][0, z], B, F, T, Tp, ldC, m * F, s)
+        if self.nm == 2:
+            H.call("nppc_scale_transpose", prec, maps[0], None, d["rawmag"], B, F, T, Tp, ldF, 0, s)
+        # 4: eight TCN blocks, the three branches batched over blockIdx.z
+        d["stats"].zero_()
+        sAct = B * Tp * TCN_HIDDEN
+        for i, dil in enumerate(TCN_DILATIONS):
+            pre = f"fb_model.sequence_model.{i}."
+            xi, xo = (i, i + 1) if train else ((0 if i == 0 else 1 + (i - 1) % 2), 1 + i % 2)
+            bi = i if train else 0
+            Xin, Xout = d["X"][xi], d["X"][xo]
+            y1, y2 = d["y1"][bi], d["y2"][bi]
+            st1, st2 = d["stats"][i, 0], d["stats"][i, 1]
+            H.call("nppc_gemm_nt", prec, EPI_PRELU_STATS, Xin, ldC, R * ldC, self.W1p[i], ldC, TCN_HIDDEN * ldC,
+                   y1, TCN_HIDDEN, sAct, self.p(pre + "conv1x1.bias"), sP, None, 0, 0, self.p(pre + "prelu1.weight"), sP,
+                   st1, B * 2, R, TCN_HIDDEN, self.KC, Tp, Tv, TCN_HIDDEN, 0, 3, s)
+            H.call("nppc_tcn_dwconv", prec, y1, y2, st1, st2, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
+                   self.p(pre + "depthwise_conv.weight"), self.p(pre + "depthwise_conv.bias"),
+                   self.p(pre + "prelu2.weight"), B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
+            H.call("nppc_tcn_gn_apply", prec, y2, d["a2"], st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"),
+                   B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
+            H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, d["a2"], TCN_HIDDEN, sAct, self.W2p[i], TCN_HIDDEN,
+                   ldC * TCN_HIDDEN, Xout, ldC, R * ldC, self.p(pre + "sconv.bias"), sP, Xin, ldC, R * ldC, None, 0,
+                   None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, s)
+        Xlast = d["X"][8 if train else 2]
+        # 5: trailing ReLU + Linear(C -> F) + ReLU
+        H.call("nppc_gemm_nt", prec, EPI_RELU, Xlast, ldC, R * ldC, self.Wfcp, ldC, ldF * ldC, d["fb"], ldF, R * ldF,
+               self.p("fb_model.fc_output_layer.bias"), sP, None, 0, 0, None, 0, None, 0, R, ldF, self.KC, Tp, Tv, F, 1,
+               3, s)
+        # 6: sub-band unfold + concat + norm + drop-band, staged time-major for the LSTM
+        if self.nm == 1:
+            src, ldS = d["X"][0, 0], ldC          # attention-scaled, normalised magnitude (fullsubnet_plus.py:203)
+        else:
+            src, ldS = d["rawmag"], ldF           # RAW padded magnitude (networks.py:133)
+        H.call("nppc_subband_mean", prec, src, ldS, d["fb"], ldF, R * ldF, self.mult, d["sbscale"], B, F, Tp, Tv,
+               self.I, s)
+        H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
+               self.nb, self.G, self.KX, s)
+        # 7: two-layer LSTM over T' steps for the B*F' sequences
+        if mtile is None:
+            mtile = pick_mtile(d["Nseq"], prec, train)
+        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile)
+        d["lstm"] = lo
+        # 8: Linear(H -> O) + re-layout + look-ahead crop
+        out = torch.empty(B, self.O, d["Fo"], T, dtype=torch.float32, device=self.dev)
+        H.call("nppc_sb_head", prec, lo["h2"], self.Whp, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
+               self.la, self.Hd, self.O, d["Fo"], s)
+        self.last = d
+        return out

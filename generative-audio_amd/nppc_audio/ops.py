@@ -1,0 +1,68 @@
+"""Thin host wrappers over the element-wise / front-end entry points of libnppc_hip.so.
+
+Each function validates shapes the way the reference call site would fail, allocates the outputs
+with torch (device memory plumbing only) and enqueues the HIP kernel on the current stream.
+"""
+import torch
+
+from . import _hip as H
+
+EPS32 = float(torch.finfo(torch.float32).eps)   # audio_zen/constant.py:8
+
+
+def _f32c(x):
+    H.require_gpu()
+    if not x.is_cuda:
+        raise RuntimeError("NPPC-audio HIP ops take device tensors")
+    return x.contiguous().float()
+
+
+def stft(wave, nfft, hop, want_mag=True):
+    """utils.py:107-147 / trainer.py:349-355: centred, periodic-hann, onesided STFT.
+    wave [B,L] -> (mag|None, real, imag) each [B,F,T]."""
+    wave = _f32c(wave)
+    if wave.dim() == 1:
+        wave = wave[None]
+    B, L = wave.shape
+    F, T = nfft // 2 + 1, 1 + L // hop
+    re = torch.empty(B, F, T, dtype=torch.float32, device=wave.device)
+    im = torch.empty_like(re)
+    mag = torch.empty_like(re) if want_mag else None
+    H.call("nppc_stft", wave, re, im, mag, B, L, nfft, hop, H.stream())
+    return mag, re, im
+
+
+def drop_band(x, num_groups=2):
+    """audio_zen/acoustics/feature.py:254-285 on [B,C,F,T]."""
+    B, C, F, T = x.shape
+    assert B > num_groups, f"Batch size = {B}, num_groups = {num_groups}. The batch size should larger than the num_groups."
+    if num_groups <= 1:
+        return x
+    x = _f32c(x)
+    Fo = (F - F % num_groups) // num_groups
+    out = torch.empty(B, C, Fo, T, dtype=torch.float32, device=x.device)
+    H.call("nppc_dropband", x, out, B, C, F, T, num_groups, H.stream())
+    return out
+
+
+def cirm_build_compress(n_re, n_im, c_re, c_im, num_groups=1):
+    """mask.py:24-54 + trainer.py:359-362: compressed cIRM in [B,2,F',T], drop-band applied."""
+    n_re, n_im, c_re, c_im = (_f32c(t) for t in (n_re, n_im, c_re, c_im))
+    B, F, T = n_re.shape
+    assert B > num_groups, f"Batch size = {B}, num_groups = {num_groups}. The batch size should larger than the num_groups."
+    Fo = F if num_groups <= 1 else (F - F % num_groups) // num_groups
+    out = torch.empty(B, 2, Fo, T, dtype=torch.float32, device=n_re.device)
+    H.call("nppc_cirm_build_compress", n_re, n_im, c_re, c_im, out, B, F, T, num_groups, EPS32, H.stream())
+    return out
+
+
+def cirm_decompress_apply_conj(crm, n_re, n_im, want_dec=False):
+    """mask.py:57-60 then utils.py:241-249 (-> :75-79 with real/imag swapped = conj(mask)*noisy).
+    crm [B,2,F,T] compressed; n_re/n_im [B,F,T] -> (dec [B,F,T,2]|None, enh_mag, enh_real, enh_imag)."""
+    crm, n_re, n_im = _f32c(crm), _f32c(n_re), _f32c(n_im)
+    B, _, F, T = crm.shape
+    emag = torch.empty(B, F, T, dtype=torch.float32, device=crm.device)
+    ere, eim = torch.empty_like(emag), torch.empty_like(emag)
+    dec = torch.empty(B, F, T, 2, dtype=torch.float32, device=crm.device) if want_dec else None
+    H.call("nppc_cirm_decompress_apply_conj", crm, n_re, n_im, dec, emag, ere, eim, B, F, T, H.stream())
+    return dec, emag, ere, eim
