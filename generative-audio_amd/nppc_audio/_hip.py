@@ -82,6 +82,12 @@ SIGS = {
     "nppc_subband_mean": [I, P, I, P, I, L, P, P, I, I, I, I, I, P],
     "nppc_subband_stage": [I, P, I, P, I, L, P, P, I, I, I, I, I, I, I, P],
     "nppc_sb_head": [I, P, P, P, P, L, I, I, I, I, I, P],
+    "nppc_gram": [P, P, P, P, P, I, I, L, P],
+    "nppc_combine": [P, P, P, P, P, P, P, I, I, L, P],
+    "nppc_gs_solve": [P, P, P, I, I, I, P],
+    "nppc_gs_bwd_solve": [P, P, P, P, I, I, I, P],
+    "nppc_loss_solve": [P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "nppc_loss_bwd_coef": [P, P, P, F, F, P, I, I, P],
 }
 _bound = set()
 
