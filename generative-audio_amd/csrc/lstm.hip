@@ -21,7 +21,8 @@ struct LstmFwdArgs {
   const float* bias1; // [4][H]  b_ih + b_hh
   const float* bias2;
   void* h2;           // [Tn][N][H]  T   (always written)
-  void* h1;           // [Tn][N][H]  T   (train)
+  void* h1T;          // [H][Tn*N]   T   (train; transposed copies for the weight-gradient GEMMs)
+  void* h2T;
   void* g1;           // [Tn][N][H][4] T (train; post-activation, order i,g,f,o)
   void* g2;
   void* c1;           // [Tn][N][H]  T   (train)
@@ -86,7 +87,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
                                            __amdgpu_buffer_rsrc_t wr, int wave_boff, int pair_bstride, int lane,
                                            T* lds_h /* + 4q*RS + ubase+n */,
                                            long rbase /* row0 + 4q */, long N, size_t ebase, T* gates_out, T* c_out,
-                                           T* h_out) {
+                                           T* h_out, T* hT_out /* + unit*R + t*N + rbase */, size_t R) {
   f32x4 ig[UB][MT];
   {
     f32x4 acc[UB][2][MT];
@@ -137,6 +138,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
           if (SAVE) {
             c_out[e] = from_f32<T>(cn);
             store_pair<T>(gates_out + e * 4 + 2, fv, ov);
+            hT_out[(size_t)(16 * ub) * R + 16 * mt + j] = from_f32<T>(hn);   // rows j = 0..3 are adjacent: 4 x T per lane
           }
         }
       }
@@ -205,8 +207,10 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
   const T* a_lane = lds + n * RS + 8 * q;
   T* hw_lane = lds + 4 * q * RS + ubase_n;
   const long rbase = row0 + 4 * q;
-  T* h1o = reinterpret_cast<T*>(a.h1);
+  T* h1T = reinterpret_cast<T*>(a.h1T);
+  T* h2T = reinterpret_cast<T*>(a.h2T);
   T* h2o = reinterpret_cast<T*>(a.h2);
+  const size_t Rtot = (size_t)a.Tn * N;
   T* g1o = reinterpret_cast<T*>(a.g1);
   T* g2o = reinterpret_cast<T*>(a.g2);
   T* c1o = reinterpret_cast<T*>(a.c1);
@@ -234,8 +238,9 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
       }
     }
     // layer 1: [x_t | h1_{t-1}]  ->  h1_t into the other half
-    layer_step<T, UB, MT, RS, H, TRAIN, TRAIN>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
-                                               g1o, c1o, h1o);
+    const size_t tbase = (size_t)ubase_n * Rtot + (size_t)t * N + rbase;
+    layer_step<T, UB, MT, RS, H, TRAIN, false>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
+                                               g1o, c1o, nullptr, TRAIN ? h1T + tbase : nullptr, Rtot);
     if (more) {
 #pragma unroll
       for (int u = 0; u < XCH; ++u) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
     __syncthreads();
     // layer 2: [h1_t | h2_{t-1}] (other half)  ->  h2_t into this half
     layer_step<T, UB, MT, RS, H, TRAIN, true>(b2, c2, a_lane + oth + KX, nk2, wr2, wb2, ps2, lane, hw_lane + cur + KX + HP, rbase, N,
-                                              ebase, g2o, c2o, h2o);
+                                              ebase, g2o, c2o, h2o, TRAIN ? h2T + tbase : nullptr, Rtot);
     // One barrier per step suffices: what step t+1 writes before its barrier (h1 -> half_p.H1,
     // x_{t+2} -> half_p.X, and after it h2 -> half_{1-p}.H2) was last READ before the barrier above
     // (layer 1 of step t) or in layer 2 of step t, which every wave finishes before it can reach
@@ -378,13 +383,13 @@ int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, co
 }
 
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                   const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2, long N, int Tn,
-                   int I, int H, void* stream) {
+                   const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
+                   int Tn, int I, int H, void* stream) {
   HCfg c;
   if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
   if (N <= 0 || Tn <= 0 || !x || !wp1 || !wp2 || !h2) return NPPC_EBADARG;
-  if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
-  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, N, Tn, kx_for(I, H)};
+  if (train && (!h1T || !h2T || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
+  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, N, Tn, kx_for(I, H)};
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16) {
     if (H == 384) return dispatch_fwd<bf16_t, 3, 8, 64>(a, mtile, train, s);
@@ -392,6 +397,303 @@ int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp
   } else if (prec == NPPC_PREC_F32) {
     if (H == 384) return dispatch_fwd<float, 3, 8, 64>(a, mtile, train, s);
     return dispatch_fwd<float, 1, 1, 32>(a, mtile, train, s);
+  }
+  return NPPC_EBADARG;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Backward recurrence (training, direction net).  One workgroup = 16 sequences, all steps (descending),
+// both layers.  Per step and layer:
+//   P: cell backward on (row, unit) pairs -> dgates tile [16][4H] (order per unit: i,g,f,o) into LDS (MFMA A operand)
+//   G: [16][4H] x Wcat[4H][Kin] on MFMA -> d(input) | d(h_prev); the tile is also written TRANSPOSED to HBM
+//      (dgT [4H][Tn*N]) so the weight-gradient GEMMs read a K-contiguous operand.
+// Backward weights are packed per wave like the forward ones (B fragment: column = input feature, k = u*4+gate).
+namespace {
+
+struct LstmBwdArgs {
+  const void* g1; const void* g2;   // [Tn][N][H][4]
+  const void* c1; const void* c2;   // [Tn][N][H]
+  const void* dh2;                  // [Tn][N][H]
+  const void* wb1; const void* wb2; // packed backward weights
+  void* dx;                         // [Tn][N][KX]
+  void* dg1T; void* dg2T;           // [4H][Tn*N]
+  long N; int Tn;
+};
+
+template <typename T, int TPW>
+__device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[TPW], const T* a_lane, int nk, __amdgpu_buffer_rsrc_t wr, int wave_boff,
+                                         int lane) {
+  typedef typename Frag<T>::type frag;
+  constexpr int FB = 512 * (int)sizeof(T);
+  auto loadb = [&](frag(&b)[TPW], int kk) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) b[i] = BFrag<T>::load(wr, lane, wave_boff + (kk * TPW + i) * FB);
+  };
+  auto compute = [&](const frag(&b)[TPW], int kk) {
+    const frag af = load_frag<T>(a_lane + 32 * kk);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = mma16(af, b[i], acc[i]);
+  };
+  frag b0[TPW], b1[TPW];
+  loadb(b0, 0);
+#pragma unroll 1
+  for (int kk = 0; kk < nk - 2; kk += 2) {
+    loadb(b1, kk + 1);
+    compute(b0, kk);
+    loadb(b0, kk + 2);
+    compute(b1, kk + 1);
+  }
+  loadb(b1, nk - 1);
+  compute(b0, nk - 2);
+  compute(b1, nk - 1);
+}
+
+template <typename T, int UB, int NW, int KX>
+__global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
+  constexpr int H = 16 * UB * NW;
+  constexpr int HP = (H + 31) / 32 * 32;
+  constexpr int NT = NW * 64;
+  constexpr int M = 16;
+  constexpr int TPR = NT / M;          // threads per row in the cell-backward phase
+  constexpr int UPT = H / TPR;         // units per thread
+  constexpr int K4 = 4 * H;            // gate columns
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int RSA = K4 + VEC;        // A tile row stride (elements)
+  constexpr int NT2 = 2 * HP / 16, NT1 = (KX + HP) / 16;
+  constexpr int TPW2 = (NT2 + NW - 1) / NW, TPW1 = (NT1 + NW - 1) / NW;
+  constexpr int nk = K4 / 32;
+  static_assert(H % TPR == 0 && nk % 2 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Abuf = reinterpret_cast<T*>(smem_raw);                                   // [16][RSA]
+  float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)M * RSA * sizeof(T));  // [16][HP]
+  float* dhrec2 = dh1buf + M * HP;                                            // [16][HP]
+
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long row0 = (long)blockIdx.x * M;
+  const long N = a.N;
+  const long R = (long)a.Tn * N;
+  for (int i = tid; i < 2 * M * HP; i += NT) dh1buf[i] = 0.f;
+  for (int i = tid; i < M * RSA; i += NT) Abuf[i] = from_f32<T>(0.f);
+
+  const int prow = tid / TPR, u0 = (tid % TPR) * UPT;
+  const bool prow_ok = row0 + prow < N;
+  float dc1[UPT], dc2[UPT];
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) dc1[i] = dc2[i] = 0.f;
+
+  const T* g1 = reinterpret_cast<const T*>(a.g1);
+  const T* g2 = reinterpret_cast<const T*>(a.g2);
+  const T* c1 = reinterpret_cast<const T*>(a.c1);
+  const T* c2 = reinterpret_cast<const T*>(a.c2);
+  const T* dh2 = reinterpret_cast<const T*>(a.dh2);
+  T* dx = reinterpret_cast<T*>(a.dx);
+  T* dg1T = reinterpret_cast<T*>(a.dg1T);
+  T* dg2T = reinterpret_cast<T*>(a.dg2T);
+  const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wb1, (unsigned)(NW * nk * TPW1 * 512 * sizeof(T)));
+  const __amdgpu_buffer_rsrc_t wr2 = make_rsrc(a.wb2, (unsigned)(NW * nk * TPW2 * 512 * sizeof(T)));
+  const int wb1 = wave * (nk * TPW1 * 512 * (int)sizeof(T));
+  const int wb2 = wave * (nk * TPW2 * 512 * (int)sizeof(T));
+  const T* a_lane = Abuf + n * RSA + 8 * q;
+  __syncthreads();
+
+  // cell backward for this thread's (row, units); dh_tot comes from LDS (+ the external grad for layer 2)
+  auto cell_bwd = [&](const T* gs, const T* cs, const float* dh_lds, const T* dh_ext, float (&dc)[UPT], int t) {
+    const size_t e = ((size_t)t * N + row0 + prow) * H + u0;
+    const size_t ep = ((size_t)(t - 1) * N + row0 + prow) * H + u0;
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      float di = 0.f, dg = 0.f, df = 0.f, dO = 0.f;
+      if (prow_ok) {
+        const float iv = to_f32<T>(gs[(e + i) * 4 + 0]), gv = to_f32<T>(gs[(e + i) * 4 + 1]);
+        const float fv = to_f32<T>(gs[(e + i) * 4 + 2]), ov = to_f32<T>(gs[(e + i) * 4 + 3]);
+        const float ct = to_f32<T>(cs[e + i]);
+        const float cp = t > 0 ? to_f32<T>(cs[ep + i]) : 0.f;
+        float dh = dh_lds[prow * HP + u0 + i];
+        if (dh_ext) dh += to_f32<T>(dh_ext[e + i]);
+        const float tc = tanh_f(ct);
+        const float dct = dh * ov * (1.f - tc * tc) + dc[i];
+        dO = dh * tc * ov * (1.f - ov);
+        di = dct * gv * iv * (1.f - iv);
+        dg = dct * iv * (1.f - gv * gv);
+        df = dct * cp * fv * (1.f - fv);
+        dc[i] = dct * fv;
+      }
+      T* ap = Abuf + prow * RSA + (u0 + i) * 4;
+      ap[0] = from_f32<T>(di);
+      ap[1] = from_f32<T>(dg);
+      ap[2] = from_f32<T>(df);
+      ap[3] = from_f32<T>(dO);
+    }
+  };
+  // transposed copy of the dgates tile: dgT[k][t*N + row0 + r], r < 16
+  auto write_T = [&](T* dgT, int t) {
+    const size_t cbase = (size_t)t * N + row0;
+    for (int k = tid; k < K4; k += NT) {
+      T* dst = dgT + (size_t)k * R + cbase;
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        if (row0 + r < N) dst[r] = Abuf[r * RSA + k];
+    }
+  };
+
+#pragma unroll 1
+  for (int t = a.Tn - 1; t >= 0; --t) {
+    // ---- layer 2
+    cell_bwd(g2, c2, dhrec2, dh2, dc2, t);
+    __syncthreads();
+    {
+      f32x4 acc[TPW2];
+#pragma unroll
+      for (int i = 0; i < TPW2; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bwd_gemm<T, TPW2>(acc, a_lane, nk, wr2, wb2, lane);
+      write_T(dg2T, t);
+#pragma unroll
+      for (int i = 0; i < TPW2; ++i) {
+        const int col = 16 * (wave * TPW2 + i) + n;
+        if (wave * TPW2 + i < NT2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            if (col < HP) dh1buf[r * HP + col] += acc[i][j];      // d h1_t from layer 2 (+ recurrent part already there)
+            else dhrec2[r * HP + col - HP] = acc[i][j];           // d h2_{t-1}
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- layer 1
+    cell_bwd(g1, c1, dh1buf, nullptr, dc1, t);
+    __syncthreads();
+    {
+      f32x4 acc[TPW1];
+#pragma unroll
+      for (int i = 0; i < TPW1; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bwd_gemm<T, TPW1>(acc, a_lane, nk, wr1, wb1, lane);
+      write_T(dg1T, t);
+#pragma unroll
+      for (int i = 0; i < TPW1; ++i) {
+        const int col = 16 * (wave * TPW1 + i) + n;
+        if (wave * TPW1 + i < NT1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            if (col < KX) {
+              if (row0 + r < N) dx[((size_t)t * N + row0 + r) * KX + col] = from_f32<T>(acc[i][j]);
+            } else {
+              dh1buf[r * HP + col - KX] = acc[i][j];              // d h1_{t-1} (recurrent)
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// packed backward weights: element (wave w, kk, tile i, lane l, j):
+//   col = 16*(w*TPW + i) + (l&15)  (input feature: layer 1: [x (K0) | h (HP)], layer 2: [h1 (HP) | h2 (HP)])
+//   k = 32*kk + 8*(l>>4) + j = u*4 + g', g' in saved order (i,g,f,o) -> torch gate block tg = {0,2,1,3}[g']
+//   value = col < K0 ? W_ih[tg*H+u][col] (col < I) : W_hh[tg*H+u][col-K0] (col-K0 < H), 0 elsewhere
+template <typename T>
+__global__ void lstm_pack_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, T* __restrict__ out,
+                                     int I, int H, int K0, int HP, int NW, int TPW) {
+  const int nk = 4 * H / 32;
+  const int ntiles = (K0 + HP) / 16;
+  const size_t total = (size_t)NW * nk * TPW * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = e & 7;
+    const int l = (e >> 3) & 63;
+    size_t f = e >> 9;
+    const int i = f % TPW; f /= TPW;
+    const int kk = f % nk;
+    const int w = (int)(f / nk);
+    const int tile = w * TPW + i;
+    const int col = 16 * tile + (l & 15);
+    const int k = 32 * kk + 8 * (l >> 4) + j;
+    const int u = k >> 2, gp = k & 3;
+    const int tg = gp == 0 ? 0 : (gp == 1 ? 2 : (gp == 2 ? 1 : 3));
+    float v = 0.f;
+    if (tile < ntiles) {
+      if (col < K0) {
+        if (col < I) v = w_ih[(size_t)(tg * H + u) * I + col];
+      } else if (col - K0 < H) {
+        v = w_hh[(size_t)(tg * H + u) * H + (col - K0)];
+      }
+    }
+    out[e] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int UB, int NW, int KX>
+static int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
+  constexpr int H = 16 * UB * NW, HP = (H + 31) / 32 * 32;
+  constexpr size_t smem = (size_t)16 * (4 * H + 16 / sizeof(T)) * sizeof(T) + (size_t)2 * 16 * HP * sizeof(float);
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  auto k = lstm2_bwd_kernel<T, UB, NW, KX>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+      hipSuccess)
+    return NPPC_ELAUNCH;
+  hipLaunchKernelGGL(k, dim3(ceil_div(a.N, 16)), dim3(NW * 64), smem, s, a);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2) {
+  HCfg c;
+  if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
+  const int KX = kx_for(I, H), HP = round_up(H, 32);
+  const int nk = 4 * H / 32;
+  const int tpw1 = ((KX + HP) / 16 + c.NW - 1) / c.NW, tpw2 = (2 * HP / 16 + c.NW - 1) / c.NW;
+  *n1 = (long)c.NW * nk * tpw1 * 512;
+  *n2 = (long)c.NW * nk * tpw2 * 512;
+  return NPPC_OK;
+}
+
+int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
+                                int I, int H, void* wb1, void* wb2, void* stream) {
+  HCfg c;
+  if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
+  const int KX = kx_for(I, H), HP = round_up(H, 32);
+  const int tpw1 = ((KX + HP) / 16 + c.NW - 1) / c.NW, tpw2 = (2 * HP / 16 + c.NW - 1) / c.NW;
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16) {
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel<bf16_t>, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (bf16_t*)wb1, I, H, KX, HP,
+                       c.NW, tpw1);
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel<bf16_t>, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (bf16_t*)wb2, H, H, HP, HP,
+                       c.NW, tpw2);
+  } else if (prec == NPPC_PREC_F32) {
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel<float>, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (float*)wb1, I, H, KX, HP, c.NW,
+                       tpw1);
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel<float>, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (float*)wb2, H, H, HP, HP, c.NW,
+                       tpw2);
+  } else {
+    return NPPC_EBADARG;
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_lstm2_bwd(int prec, const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2,
+                   const void* wb1, const void* wb2, void* dx, void* dg1T, void* dg2T, long N, int Tn, int I, int H,
+                   void* stream) {
+  HCfg c;
+  if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
+  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1T || !dg2T || N <= 0 || Tn <= 0) return NPPC_EBADARG;
+  LstmBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, N, Tn};
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16) {
+    if (H == 384) return launch_bwd<bf16_t, 3, 8, 64>(a, s);
+    return launch_bwd<bf16_t, 1, 1, 32>(a, s);
+  } else if (prec == NPPC_PREC_F32) {
+    if (H == 384) return launch_bwd<float, 3, 8, 64>(a, s);
+    return launch_bwd<float, 1, 1, 32>(a, s);
   }
   return NPPC_EBADARG;
 }

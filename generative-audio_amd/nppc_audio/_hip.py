@@ -67,7 +67,10 @@ PI = ctypes.POINTER(c_i)
 SIGS = {
     "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
     "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
-    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
+    "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
+    "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "nppc_stft": [P, P, P, P, I, I, I, I, P],
     "nppc_dropband": [P, P, I, I, I, I, I, P],
     "nppc_cirm_build_compress": [P, P, P, P, P, I, I, I, I, F, P],

@@ -44,7 +44,8 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
     dt, dev = x_tm.dtype, x_tm.device
     out = {"h2": torch.empty(Tn, N, Hd, dtype=dt, device=dev)}
     if train:
-        out["h1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
+        out["h1T"] = torch.empty(Hd, Tn * N, dtype=dt, device=dev)
+        out["h2T"] = torch.empty(Hd, Tn * N, dtype=dt, device=dev)
         out["c1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
         out["c2"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
         out["g1"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
@@ -52,6 +53,36 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
     H.call("nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
-           out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
-           H.stream())
+           out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn,
+           packed.I, Hd, H.stream())
     return out
+
+
+class PackedLSTMBwd:
+    """Backward (transposed) packing: B fragment column = input feature, k = unit*4 + gate(i,g,f,o)."""
+
+    def __init__(self, I, Hd, prec, device):
+        n1, n2 = ctypes.c_long(), ctypes.c_long()
+        H.call("nppc_lstm2_bwd_packed_elems", I, Hd, ctypes.byref(n1), ctypes.byref(n2))
+        self.I, self.Hd, self.prec = I, Hd, prec
+        dt = H.dtype_of(prec)
+        self.wb1 = torch.empty(n1.value, dtype=dt, device=device)
+        self.wb2 = torch.empty(n2.value, dtype=dt, device=device)
+
+    def pack(self, w_ih0, w_hh0, w_ih1, w_hh1):
+        ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, w_ih1, w_hh1)]
+        H.call("nppc_lstm2_pack_weights_bwd", self.prec, *ws, self.I, self.Hd, self.wb1, self.wb2, H.stream())
+        return self
+
+
+def lstm2_backward(saved, dh2, packed_bwd, kx):
+    """saved = lstm2_forward(train=True) dict; dh2 [Tn][N][H] -> dx [Tn][N][kx], dg1T, dg2T [4H][Tn*N]
+    (transposed gate gradients, row k = unit*4 + gate in (i,g,f,o) order)."""
+    Tn, N, Hd = saved["h2"].shape
+    dt, dev = dh2.dtype, dh2.device
+    dx = torch.empty(Tn, N, kx, dtype=dt, device=dev)
+    dg1T = torch.empty(4 * Hd, Tn * N, dtype=dt, device=dev)
+    dg2T = torch.empty(4 * Hd, Tn * N, dtype=dt, device=dev)
+    H.call("nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
+           packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, H.stream())
+    return dx, dg1T, dg2T

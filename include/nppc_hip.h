@@ -22,10 +22,11 @@ int nppc_lstm2_packed_elems(int I, int H, long* n1, long* n2, int* kx);
 int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, const float* b_ih0, const float* b_hh0,
                             const float* w_ih1, const float* w_hh1, const float* b_ih1, const float* b_hh1, int I, int H,
                             void* wp1, void* wp2, float* bias1, float* bias2, void* stream);
-/* x [Tn][N][kx]; h2 (and, when train, h1,c1,c2 [Tn][N][H], g1,g2 [Tn][N][H][4]) time-major. */
+/* x [Tn][N][kx]; h2 [Tn][N][H] time-major; when train also c1,c2 [Tn][N][H], g1,g2 [Tn][N][H][4] (i,g,f,o) and the
+ * transposed hidden states h1T,h2T [H][Tn*N] that the weight-gradient GEMMs consume. */
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                   const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2, long N, int Tn,
-                   int I, int H, void* stream);
+                   const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
+                   int Tn, int I, int H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,9 +45,10 @@ def test_lstm_fwd_f32_matches_oracle(Hd, I, train):
     assert err < 2e-5, err          # fp32 tolerance: exact-f32 MFMA, rcp/exp 1-ulp activations
     if train:
         # saved state: h1 and the post-activation gates/cell of both layers against the explicit recurrence
-        h1 = out["h1"].float().cpu().permute(1, 0, 2)
-        Pl0 = dict(P)
+        h1 = out["h1T"].float().cpu().reshape(Hd, Tn, N).permute(2, 1, 0)
         ref_h1 = _layer_out(x, P, 0)
+        h2t = out["h2T"].float().cpu().reshape(Hd, Tn, N).permute(2, 1, 0)
+        assert (h2t - got).abs().max().item() < 1e-6
         assert (h1 - ref_h1).abs().max().item() < 2e-5
         g2 = out["g2"].float().cpu()
         assert torch.isfinite(g2).all() and g2[..., 0].min() >= 0 and g2[..., 0].max() <= 1   # i
@@ -89,3 +90,57 @@ def test_lstm_fwd_bf16_train_saves_consistent_state():
     c2 = out["c2"].float().cpu().permute(1, 0, 2)
     o2 = out["g2"].float().cpu()[..., 3].permute(1, 0, 2)
     assert (o2 * torch.tanh(c2) - got).abs().max().item() < 2e-2
+
+
+def _unperm(dgT, Hd):
+    """[4H (k = u*4 + g', g' in i,g,f,o)][R] -> torch gate-row order [4H (i,f,g,o blocks)][R]"""
+    R = dgT.shape[1]
+    d = dgT.reshape(Hd, 4, R)
+    return torch.cat([d[:, 0], d[:, 2], d[:, 1], d[:, 3]], dim=0)
+
+
+@pytest.mark.parametrize("Hd,I,prec,tol", [(16, 10, 1, 2e-4), (384, 34, 1, 2e-4), (384, 34, 0, 4e-2), (16, 10, 0, 4e-2)])
+def test_lstm_bwd_matches_autograd(Hd, I, prec, tol):
+    from nppc_audio import _hip as H
+    from nppc_audio.ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_forward, lstm2_backward
+    N, Tn = (37, 9) if Hd == 16 else (40, 11)
+    P = _weights(I, Hd, 3)
+    pre = "sb_model.sequence_model."
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Tn, I, generator=g)
+    G = torch.randn(N, Tn, Hd, generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    (R.lstm2_steps(xr, Pr, "sb_model.sequence_model") * G).sum().backward()
+
+    dev = torch.device("cuda")
+    dt = H.dtype_of(prec)
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1",
+             "bias_hh_l1")
+    pk = PackedLSTM(I, Hd, prec, dev).pack(*[P[pre + n].to(dev) for n in names])
+    pb = PackedLSTMBwd(I, Hd, prec, dev).pack(*[P[pre + n].to(dev) for n in
+                                                 ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")])
+    xt = torch.zeros(Tn, N, pk.kx, dtype=dt, device=dev)
+    xt[:, :, :I] = x.permute(1, 0, 2).to(dev)
+    saved = lstm2_forward(xt, pk, True, 1)
+    dh2 = G.permute(1, 0, 2).contiguous().to(dev).to(dt)
+    dx, dg1T, dg2T = lstm2_backward(saved, dh2, pb, pk.kx)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+    got_dx = dx.float().cpu()[:, :, :I].permute(1, 0, 2)
+    assert rel(got_dx, xr.grad) < tol, rel(got_dx, xr.grad)
+    d1 = _unperm(dg1T.float().cpu(), Hd)                    # [4H][R], R index = t*N + n
+    d2 = _unperm(dg2T.float().cpu(), Hd)
+    xf = x.permute(1, 0, 2).reshape(Tn * N, I)
+    h1 = saved["h1T"].float().cpu().t()                      # [R][H]
+    h2 = saved["h2T"].float().cpu().t()
+    checks = {
+        "weight_ih_l0": d1 @ xf, "weight_hh_l0": d1[:, N:] @ h1[:-N], "bias_ih_l0": d1.sum(1), "bias_hh_l0": d1.sum(1),
+        "weight_ih_l1": d2 @ h1, "weight_hh_l1": d2[:, N:] @ h2[:-N], "bias_ih_l1": d2.sum(1), "bias_hh_l1": d2.sum(1),
+    }
+    for n, got in checks.items():
+        r = rel(got, Pr[pre + n].grad)
+        assert r < tol, (n, r)
