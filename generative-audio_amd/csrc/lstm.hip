@@ -30,6 +30,7 @@ struct LstmFwdArgs {
   long N;
   int Tn;
   int KX;
+  long Np;            // transposed outputs: column of (t, n) is t*Np + n, row stride Tn*Np (Np >= N, pad columns stay zero)
 };
 
 // One gate PAIR (gp = 0: i,g   gp = 1: f,o) of one layer:  acc[ub][s][mt] += A[16mt.., koff..] * Wpair
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
   T* h1T = reinterpret_cast<T*>(a.h1T);
   T* h2T = reinterpret_cast<T*>(a.h2T);
   T* h2o = reinterpret_cast<T*>(a.h2);
-  const size_t Rtot = (size_t)a.Tn * N;
+  const size_t Rtot = (size_t)a.Tn * a.Np;
   T* g1o = reinterpret_cast<T*>(a.g1);
   T* g2o = reinterpret_cast<T*>(a.g2);
   T* c1o = reinterpret_cast<T*>(a.c1);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
       }
     }
     // layer 1: [x_t | h1_{t-1}]  ->  h1_t into the other half
-    const size_t tbase = (size_t)ubase_n * Rtot + (size_t)t * N + rbase;
+    const size_t tbase = (size_t)ubase_n * Rtot + (size_t)t * a.Np + rbase;
     layer_step<T, UB, MT, RS, H, TRAIN, false>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
                                                g1o, c1o, nullptr, TRAIN ? h1T + tbase : nullptr, Rtot);
     if (more) {
@@ -384,12 +385,13 @@ int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, co
 
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
                    const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
-                   int Tn, int I, int H, void* stream) {
+                   int Tn, int I, int H, long Np, void* stream) {
   HCfg c;
   if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
   if (N <= 0 || Tn <= 0 || !x || !wp1 || !wp2 || !h2) return NPPC_EBADARG;
   if (train && (!h1T || !h2T || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
-  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, N, Tn, kx_for(I, H)};
+  if (train && Np < N) return NPPC_EBADARG;
+  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, N, Tn, kx_for(I, H), Np};
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16) {
     if (H == 384) return dispatch_fwd<bf16_t, 3, 8, 64>(a, mtile, train, s);
@@ -418,8 +420,8 @@ struct LstmBwdArgs {
   const void* dh2;                  // [Tn][N][H]
   const void* wb1; const void* wb2; // packed backward weights
   void* dx;                         // [Tn][N][KX]
-  void* dg1T; void* dg2T;           // [4H][Tn*N]
-  long N; int Tn;
+  void* dg1T; void* dg2T;           // [4H][Tn*Np]  column of (t, n) = t*Np + n
+  long N; int Tn; long Np;
 };
 
 template <typename T, int TPW>
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long row0 = (long)blockIdx.x * M;
   const long N = a.N;
-  const long R = (long)a.Tn * N;
+  const long R = (long)a.Tn * a.Np;
   for (int i = tid; i < 2 * M * HP; i += NT) dh1buf[i] = 0.f;
   for (int i = tid; i < M * RSA; i += NT) Abuf[i] = from_f32<T>(0.f);
 
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
   };
   // transposed copy of the dgates tile: dgT[k][t*N + row0 + r], r < 16
   auto write_T = [&](T* dgT, int t) {
-    const size_t cbase = (size_t)t * N + row0;
+    const size_t cbase = (size_t)t * a.Np + row0;
     for (int k = tid; k < K4; k += NT) {
       T* dst = dgT + (size_t)k * R + cbase;
 #pragma unroll
@@ -682,11 +684,12 @@ int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0
 
 int nppc_lstm2_bwd(int prec, const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2,
                    const void* wb1, const void* wb2, void* dx, void* dg1T, void* dg2T, long N, int Tn, int I, int H,
-                   void* stream) {
+                   long Np, void* stream) {
   HCfg c;
   if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
   if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1T || !dg2T || N <= 0 || Tn <= 0) return NPPC_EBADARG;
-  LstmBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, N, Tn};
+  if (Np < N) return NPPC_EBADARG;
+  LstmBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, N, Tn, Np};
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16) {
     if (H == 384) return launch_bwd<bf16_t, 3, 8, 64>(a, s);

@@ -126,9 +126,123 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------- TSSE backward (direction net: attention weights train)
+// X0[b][t][coff+c] = x[b][c][t] * ns_b * sg[b][c]  ->  dsg[b][c] = ns_b * sum_t dX0[b][t][coff+c] * x[b][c][t]
+template <typename T>
+__global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ dX0, const float* __restrict__ x,
+                                                          const float* __restrict__ ns, float* __restrict__ dsg, int C, int Tn,
+                                                          int Tp, int ld, int coff) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* xr = x + ((size_t)b * C + c) * Tn;
+  const T* dp = dX0 + (size_t)b * Tp * ld + coff + c;
+  float s = 0.f;
+  for (int t = 0; t < Tn; ++t) s += to_f32<T>(dp[(size_t)t * ld]) * xr[t];
+  dsg[(size_t)b * C + c] = ns[b] * s;
+}
+
+struct TsseG {
+  float* cw[3];
+  float* cb[3];
+  float* fcw; float* fcb; float* w1; float* b1; float* w2; float* b2;
+};
+
+// one workgroup per sample: backprop dsg through sigmoid/fc2/relu/fc1/feature_concate_fc/relu/conv-means;
+// parameter gradients are shared by all samples (and by the noisy/enhanced calls) -> fp32 atomics
+__global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
+                                                           TsseW w, TsseG g, const float* __restrict__ ns_in,
+                                                           const float* __restrict__ pre, const float* __restrict__ sq,
+                                                           const float* __restrict__ h1, const float* __restrict__ sg,
+                                                           const float* __restrict__ dsg, int C, int C2, int T, int la) {
+  __shared__ float da2[TSSE_MAXC];
+  __shared__ float da1[TSSE_MAXC / 2];
+  __shared__ float dsq[TSSE_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Tp = T + la;
+  const float ns = ns_in[b];
+  for (int c = tid; c < C; c += 256) {
+    const float s = sg[(size_t)b * C + c];
+    const float d = dsg[(size_t)b * C + c] * s * (1.f - s);
+    da2[c] = d;
+    atomicAdd(g.b2 + c, d);
+  }
+  __syncthreads();
+  for (int e = tid; e < C * C2; e += 256) {
+    const int c = e / C2, j = e % C2;
+    atomicAdd(g.w2 + e, da2[c] * h1[(size_t)b * C2 + j]);
+  }
+  for (int j = tid; j < C2; j += 256) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += w.w2[(size_t)c * C2 + j] * da2[c];
+    a = h1[(size_t)b * C2 + j] > 0.f ? a : 0.f;
+    da1[j] = a;
+    atomicAdd(g.b1 + j, a);
+  }
+  __syncthreads();
+  for (int e = tid; e < C2 * C; e += 256) {
+    const int j = e / C, c = e % C;
+    atomicAdd(g.w1 + e, da1[j] * sq[(size_t)b * C + c]);
+  }
+  float fsum[3] = {0.f, 0.f, 0.f}, bsum = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int j = 0; j < C2; ++j) a += w.w1[(size_t)j * C + c] * da1[j];
+    dsq[c] = a;
+    bsum += a;
+    const float* xr = x + ((size_t)b * C + c) * T;
+    const double tot = rowsum[(size_t)b * C + c];
+    for (int i = 0; i < 3; ++i) {
+      const float pv = pre[((size_t)b * C + c) * 3 + i];
+      fsum[i] += a * fmaxf(pv, 0.f);
+      const float dp = pv > 0.f ? a * w.fcw[i] : 0.f;
+      if (dp != 0.f) {
+        atomicAdd(g.cb[i] + c, dp);
+        const int ks = w.ks[i];
+        const int Lout = Tp - ks + 1;
+        for (int k = 0; k < ks; ++k) {
+          double prf = 0.0, suf = 0.0;
+          for (int t = 0; t < k; ++t) prf += (t < T) ? (double)xr[t] : 0.0;
+          for (int m = 0; m < ks - 1 - k; ++m) {
+            const int t = Tp - 1 - m;
+            suf += (t < T && t >= 0) ? (double)xr[t] : 0.0;
+          }
+          atomicAdd(g.cw[i] + c * ks + k, dp * ns * (float)((tot - prf - suf) / Lout));
+        }
+      }
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const float v = wave_sum(fsum[i]);
+    if ((tid & 63) == 0) atomicAdd(g.fcw + i, v);
+  }
+  const float v = wave_sum(bsum);
+  if ((tid & 63) == 0) atomicAdd(g.fcb, v);
+}
+
 }  // namespace
 
 extern "C" {
+
+int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsum, const float* cw0, const float* cw1,
+                  const float* cw2, int ks0, int ks1, int ks2, const float* fcw, const float* w1, const float* w2,
+                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws,
+                  float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1, float* g_cw2, float* g_cb2, float* g_fcw,
+                  float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int C, int T, int look_ahead, int Tp,
+                  int ld, int coff, void* stream) {
+  if (!dX0 || !x || !rowsum || !dsg_ws || B <= 0 || C > TSSE_MAXC) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g1(ceil_div(C, 256), B);
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
+  else
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
+  TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
+  TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(256), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, C, C / 2, T,
+                     look_ahead);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
 
 int nppc_rowsum(const float* x, double* sums, long R, int T, void* stream) {
   if (!x || !sums || R <= 0 || T <= 0) return NPPC_EBADARG;

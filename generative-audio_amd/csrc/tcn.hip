@@ -11,7 +11,7 @@
 
 namespace {
 
-enum { EPI_PLAIN = 0, EPI_PRELU_STATS = 1, EPI_RESIDUAL = 2, EPI_RELU = 3 };
+enum { EPI_PLAIN = 0, EPI_PRELU_STATS = 1, EPI_RESIDUAL = 2, EPI_RELU = 3, EPI_PLAIN_F32 = 4, EPI_MASK_POS = 5 };
 
 struct GemmArgs {
   const void* A; long lda; long strideA;   // [R][lda]   (strides in elements, per batch z)
@@ -25,6 +25,7 @@ struct GemmArgs {
   int Tp, Tv;                              // rows with (row % Tp) >= Tv are padding: forced to zero
   int Nv;                                  // columns >= Nv are padding: forced to zero
   int relu_in;                             // apply ReLU to A on load (TCN trailing nn.ReLU before the Linear)
+  int ksplit;                              // >1: blockIdx.z = batch*ksplit + s; slice s covers K elements [s*K, (s+1)*K)
 };
 
 template <typename T> __device__ __forceinline__ typename Frag<T>::type relu_frag(typename Frag<T>::type f);
@@ -49,10 +50,12 @@ template <> __device__ __forceinline__ f32x8 relu_frag<float>(f32x8 f) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   typedef typename Frag<T>::type frag;
-  const int z = blockIdx.z;
-  const T* A = reinterpret_cast<const T*>(g.A) + (size_t)z * g.strideA;
-  const T* B = reinterpret_cast<const T*>(g.B) + (size_t)z * g.strideB;
-  T* C = reinterpret_cast<T*>(g.C) + (size_t)z * g.strideC;
+  const int ks = g.ksplit > 1 ? g.ksplit : 1;
+  const int z = blockIdx.z / ks, ksl = blockIdx.z % ks;
+  const T* A = reinterpret_cast<const T*>(g.A) + (size_t)z * g.strideA + (size_t)ksl * g.K;
+  const T* B = reinterpret_cast<const T*>(g.B) + (size_t)z * g.strideB + (size_t)ksl * g.K;
+  T* C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.z * g.strideC;
+  float* Cf = reinterpret_cast<float*>(g.C) + (size_t)blockIdx.z * g.strideC;   // EPI_PLAIN_F32: fp32 output (split-K slabs)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
   const int r0 = blockIdx.x * 128 + wave * 32, c0 = blockIdx.y * 64;
   const T* ap = A + (size_t)(r0 + n) * g.lda + 8 * q;
@@ -120,7 +123,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
           const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
           v += to_f32<T>(res[(size_t)row * g.ldres + col]);
         }
+        if (EPI == EPI_MASK_POS) {
+          const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+          if (!(to_f32<T>(res[(size_t)row * g.ldres + col]) > 0.f)) v = 0.f;
+        }
         if (!valid) v = 0.f;
+        if (EPI == EPI_PLAIN_F32) {
+          Cf[(size_t)row * g.ldc + col] = v;
+          continue;
+        }
         const T o = from_f32<T>(v);
         C[(size_t)row * g.ldc + col] = o;
         if (EPI == EPI_PRELU_STATS) {
@@ -262,14 +273,16 @@ extern "C" {
 int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
                  long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
                  long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
-                 int batch, void* stream) {
+                 int batch, int ksplit, void* stream) {
   if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0 || batch <= 0) return NPPC_EBADARG;
   if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   if (epi == EPI_PRELU_STATS && (!slope || !stats)) return NPPC_EBADARG;
-  if (epi == EPI_RESIDUAL && !res) return NPPC_EBADARG;
+  if ((epi == EPI_RESIDUAL || epi == EPI_MASK_POS) && !res) return NPPC_EBADARG;
+  if (ksplit < 1) ksplit = 1;
+  if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
-             R, N, K, Tp, Tv, Nv, relu_in};
-  dim3 grid(R / 128, N / 64, batch);
+             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit};
+  dim3 grid(R / 128, N / 64, batch * ksplit);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(TT, E) hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), grid, dim3(256), 0, s, g)
   if (prec == NPPC_PREC_BF16) {
@@ -278,6 +291,8 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
       case EPI_PRELU_STATS: LAUNCH(bf16_t, EPI_PRELU_STATS); break;
       case EPI_RESIDUAL: LAUNCH(bf16_t, EPI_RESIDUAL); break;
       case EPI_RELU: LAUNCH(bf16_t, EPI_RELU); break;
+      case EPI_PLAIN_F32: LAUNCH(bf16_t, EPI_PLAIN_F32); break;
+      case EPI_MASK_POS: LAUNCH(bf16_t, EPI_MASK_POS); break;
       default: return NPPC_EBADARG;
     }
   } else if (prec == NPPC_PREC_F32) {
@@ -286,6 +301,8 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
       case EPI_PRELU_STATS: LAUNCH(float, EPI_PRELU_STATS); break;
       case EPI_RESIDUAL: LAUNCH(float, EPI_RESIDUAL); break;
       case EPI_RELU: LAUNCH(float, EPI_RELU); break;
+      case EPI_PLAIN_F32: LAUNCH(float, EPI_PLAIN_F32); break;
+      case EPI_MASK_POS: LAUNCH(float, EPI_MASK_POS); break;
       default: return NPPC_EBADARG;
     }
   } else {

@@ -1,0 +1,233 @@
+// Backward of the TCNBlock's normalisation / activation / depthwise stages (the 1x1-conv gradients are NT GEMMs
+// in tcn.hip on transposed operands).  Reference forward: audio_zen/model/module/causal_conv.py:96-108.
+// All tensors [z][B][Tp][C] time-major (C = 512 hidden channels), per-channel parameter gradients are
+// accumulated with fp32 atomics (one partial per workgroup), per-sample GroupNorm sums in fp64.
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+constexpr int RPB = 32;   // frames per workgroup
+
+struct GnCtx {
+  float mean, rstd;
+};
+__device__ __forceinline__ GnCtx gn_ctx(const double* st, int b, double cnt, float eps) {
+  const double m = st[b * 2] / cnt;
+  const double var = st[b * 2 + 1] / cnt - m * m;
+  return {(float)m, (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps))};
+}
+
+// pass 1 of GroupNorm backward:  S[b] = (sum dxh, sum dxh*xh), dgamma[c] += sum dA*xh, dbeta[c] += sum dA
+//   xh = (y - mean) * rstd,  dxh = dA * gamma
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ dA, const T* __restrict__ y,
+                                                            const double* __restrict__ st, const float* __restrict__ gamma,
+                                                            double* __restrict__ S, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int Cc, int Tp, int Tv, float eps,
+                                                            long sAct, long sSt, long sP) {
+  extern __shared__ float sm[];   // [2][Cc] channel partials
+  const int z = blockIdx.z, b = blockIdx.y;
+  dA += (size_t)z * sAct; y += (size_t)z * sAct;
+  st += (size_t)z * sSt; S += (size_t)z * sSt;
+  gamma += (size_t)z * sP; dgamma += (size_t)z * sP; dbeta += (size_t)z * sP;
+  const GnCtx c = gn_ctx(st, b, (double)Cc * Tv, eps);
+  for (int i = threadIdx.x; i < 2 * Cc; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int cpr = Cc / 8, rpi = 256 / cpr;
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  float s1 = 0.f, s2 = 0.f, dg[8], db[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dg[i] = db[i] = 0.f;
+  if (tl < rpi) {
+    for (int t = blockIdx.x * RPB + tl; t < (blockIdx.x + 1) * RPB && t < Tv; t += rpi) {
+      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = to_f32<T>(dA[o + i]);
+        const float xh = (to_f32<T>(y[o + i]) - c.mean) * c.rstd;
+        const float dxh = d * gamma[c8 + i];
+        s1 += dxh;
+        s2 += dxh * xh;
+        dg[i] += d * xh;
+        db[i] += d;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(&sm[c8 + i], dg[i]);
+      atomicAdd(&sm[Cc + c8 + i], db[i]);
+    }
+  }
+  const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(S + b * 2, d1);
+    atomicAdd(S + b * 2 + 1, d2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cc; i += 256) {
+    atomicAdd(dgamma + i, sm[i]);
+    atomicAdd(dbeta + i, sm[Cc + i]);
+  }
+}
+
+// pass 2: dy = rstd * (dxh - S1/cnt - xh * S2/cnt);  PReLU backward through y = prelu(pre):
+//   dpre = y > 0 ? dy : a*dy;   da += sum_{y<0} dy * y / a      (pre = y/a for y < 0; assumes slope a > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_prelu_bwd_kernel(const T* __restrict__ dA, const T* __restrict__ y,
+                                                           const double* __restrict__ st, const float* __restrict__ gamma,
+                                                           const double* __restrict__ S, const float* __restrict__ slope,
+                                                           T* __restrict__ dpre, float* __restrict__ dslope, int Cc, int Tp,
+                                                           int Tv, float eps, long sAct, long sSt, long sP) {
+  const int z = blockIdx.z, b = blockIdx.y;
+  dA += (size_t)z * sAct; y += (size_t)z * sAct; dpre += (size_t)z * sAct;
+  st += (size_t)z * sSt; S += (size_t)z * sSt;
+  gamma += (size_t)z * sP;
+  const float a = slope[(size_t)z * sP];
+  const double cnt = (double)Cc * Tv;
+  const GnCtx c = gn_ctx(st, b, cnt, eps);
+  const float m1 = (float)(S[b * 2] / cnt), m2 = (float)(S[b * 2 + 1] / cnt);
+  const int cpr = Cc / 8, rpi = 256 / cpr;
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  float da = 0.f;
+  if (tl < rpi) {
+    for (int t = blockIdx.x * RPB + tl; t < (blockIdx.x + 1) * RPB && t < Tp; t += rpi) {
+      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float out = 0.f;
+        if (t < Tv) {
+          const float yv = to_f32<T>(y[o + i]);
+          const float xh = (yv - c.mean) * c.rstd;
+          const float dxh = to_f32<T>(dA[o + i]) * gamma[c8 + i];
+          const float dy = c.rstd * (dxh - m1 - xh * m2);
+          if (yv > 0.f) out = dy;
+          else { out = a * dy; da += dy * yv / a; }
+        }
+        dpre[o + i] = from_f32<T>(out);
+      }
+    }
+  }
+  const float ds = wave_sum(da);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dslope + (size_t)z * sP, ds);
+}
+
+// depthwise conv backward.  forward: u[t] = bd + sum_k wd[k] * zz[t + (k-1)d],  zz = GN1(y1) on valid frames else 0
+//   dz[t']  = sum_k wd[k] * du[t' - (k-1)d]         (valid t', source frame inside [0, Tv))
+//   dwd[k] += sum_t du[t] * zz[t + (k-1)d];   dbd += sum_t du[t]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ du, const T* __restrict__ y1,
+                                                         const double* __restrict__ st1, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ wd,
+                                                         T* __restrict__ dz, float* __restrict__ dwd, float* __restrict__ dbd,
+                                                         int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt,
+                                                         long sP) {
+  extern __shared__ float sm[];   // [4][Cc]: dwd k=0..2, dbd
+  const int z = blockIdx.z, b = blockIdx.y;
+  du += (size_t)z * sAct; y1 += (size_t)z * sAct; dz += (size_t)z * sAct;
+  st1 += (size_t)z * sSt;
+  gamma += (size_t)z * sP; beta += (size_t)z * sP; wd += (size_t)z * sP; dwd += (size_t)z * sP; dbd += (size_t)z * sP;
+  const GnCtx c = gn_ctx(st1, b, (double)Cc * Tv, eps);
+  for (int i = threadIdx.x; i < 4 * Cc; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int cpr = Cc / 8, rpi = 256 / cpr;
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  float aw[3][8], ab[8], g8[8], be8[8], w8[3][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ab[i] = 0.f;
+    g8[i] = gamma[c8 + i] * c.rstd;
+    be8[i] = beta[c8 + i] - c.mean * g8[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { aw[k][i] = 0.f; w8[k][i] = wd[(c8 + i) * 3 + k]; }
+  }
+  if (tl < rpi) {
+    for (int t = blockIdx.x * RPB + tl; t < (blockIdx.x + 1) * RPB && t < Tp; t += rpi) {
+      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+      float out[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = 0.f;
+      if (t < Tv) {
+        float duv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { duv[i] = to_f32<T>(du[o + i]); ab[i] += duv[i]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int ts = t + (k - 1) * dil;       // forward source frame of tap k for output frame t
+          if (ts >= 0 && ts < Tv) {
+            const size_t os = ((size_t)b * Tp + ts) * Cc + c8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) aw[k][i] += duv[i] * (to_f32<T>(y1[os + i]) * g8[i] + be8[i]);
+          }
+          const int tu = t - (k - 1) * dil;       // output frame whose tap k reads frame t
+          if (tu >= 0 && tu < Tv) {
+            const size_t ou = ((size_t)b * Tp + tu) * Cc + c8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out[i] += w8[k][i] * to_f32<T>(du[ou + i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dz[o + i] = from_f32<T>(out[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) atomicAdd(&sm[k * Cc + c8 + i], aw[k][i]);
+      atomicAdd(&sm[3 * Cc + c8 + i], ab[i]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cc; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(dwd + i * 3 + k, sm[k * Cc + i]);
+    atomicAdd(dbd + i, sm[3 * Cc + i]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nppc_tcn_gn_bwd(int prec, const void* dA, const void* y, const double* st, const float* gamma, const float* slope,
+                    double* S, void* dpre, float* dgamma, float* dbeta, float* dslope, int B, int Cc, int Tp, int Tv, float eps,
+                    long sAct, long sSt, long sP, int batch, void* stream) {
+  if (!dA || !y || !st || !gamma || !slope || !S || !dpre || !dgamma || !dbeta || !dslope || Cc % 8 || Cc / 8 > 256)
+    return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(S, 0, sizeof(double) * 2 * B * batch, s) != hipSuccess) return NPPC_ELAUNCH;   // S laid out [batch][B][2], sSt = 2B
+  dim3 g1(ceil_div(Tv, RPB), B, batch), g2(ceil_div(Tp, RPB), B, batch);
+  const size_t smem = (size_t)2 * Cc * sizeof(float);
+  if (prec == NPPC_PREC_BF16) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), smem, s, (const bf16_t*)dA, (const bf16_t*)y, st, gamma, S,
+                       dgamma, dbeta, Cc, Tp, Tv, eps, sAct, sSt, sP);
+    hipLaunchKernelGGL(gn_prelu_bwd_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)dA, (const bf16_t*)y, st, gamma, S,
+                       slope, (bf16_t*)dpre, dslope, Cc, Tp, Tv, eps, sAct, sSt, sP);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g1, dim3(256), smem, s, (const float*)dA, (const float*)y, st, gamma, S,
+                       dgamma, dbeta, Cc, Tp, Tv, eps, sAct, sSt, sP);
+    hipLaunchKernelGGL(gn_prelu_bwd_kernel<float>, g2, dim3(256), 0, s, (const float*)dA, (const float*)y, st, gamma, S, slope,
+                       (float*)dpre, dslope, Cc, Tp, Tv, eps, sAct, sSt, sP);
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* st1, const float* gamma, const float* beta,
+                        const float* wd, void* dz, float* dwd, float* dbd, int B, int Cc, int Tp, int Tv, int dil, float eps,
+                        long sAct, long sSt, long sP, int batch, void* stream) {
+  if (!du || !y1 || !st1 || !gamma || !beta || !wd || !dz || !dwd || !dbd || Cc % 8 || Cc / 8 > 256) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(ceil_div(Tp, RPB), B, batch);
+  const size_t smem = (size_t)4 * Cc * sizeof(float);
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(dwconv_bwd_kernel<bf16_t>, g, dim3(256), smem, s, (const bf16_t*)du, (const bf16_t*)y1, st1, gamma, beta,
+                       wd, (bf16_t*)dz, dwd, dbd, Cc, Tp, Tv, dil, eps, sAct, sSt, sP);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_kernel<float>, g, dim3(256), smem, s, (const float*)du, (const float*)y1, st1, gamma, beta, wd,
+                       (float*)dz, dwd, dbd, Cc, Tp, Tv, dil, eps, sAct, sSt, sP);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// Training-only helpers of the direction net: transposes / column sums feeding the weight-gradient GEMMs,
+// head backward, sub-band staging backward, split-K slab reduction into the parameter gradients, Adam.
+// Reference: the autograd of nppc_audio/networks.py:63-163 + torch.optim.Adam (nppc_audio/trainer.py:64-69,102-104).
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+// out[c][r] = in[r][c] (optionally relu'd), batched over blockIdx.z
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols,
+                                                        long ld_in, long ld_out, long sIn, long sOut, int relu) {
+  __shared__ float tile[32][33];
+  in += (size_t)blockIdx.z * sIn;
+  out += (size_t)blockIdx.z * sOut;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) v = to_f32<T>(in[(size_t)r * ld_in + c]);
+    if (relu) v = fmaxf(v, 0.f);
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * ld_out + r] = from_f32<T>(tile[tx][i]);
+  }
+}
+
+// out[c] += sum_r M[r][c]   (fp32 atomics; one partial per block), batched over blockIdx.z
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ M, float* __restrict__ out, int rows, int cols,
+                                                     long ld, long sM, long sOut, int rows_per_block) {
+  M += (size_t)blockIdx.z * sM;
+  out += (size_t)blockIdx.z * sOut;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += to_f32<T>(M[(size_t)r * ld + c]);
+  atomicAdd(out + c, s);
+}
+
+// ---------------------------------------------------------------- head backward
+// dh2[t][n][u] = sum_o dY[t][n][o] * Wh[o][u],   dY[t][n][o] = dout[bo][o][fo][t-la] (0 for t < la)
+// one wave = 16 rows; A fragment gathered from dout (K = O <= 32), B = WhT packed [Hd][32].
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restrict__ dout, const T* __restrict__ whT,
+                                                          T* __restrict__ dh2, long Nseq, int Tn, int la, int Hd, int O,
+                                                          int Fo) {
+  typedef typename Frag<T>::type frag;
+  const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+  const long tiles_per_t = (Nseq + 15) / 16;
+  const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= tiles_per_t * Tn) return;
+  const int t = (int)(tile / tiles_per_t);
+  const long n0 = (tile % tiles_per_t) * 16;
+  const int To = Tn - la;
+  frag a;
+  {
+    const long nn = n0 + n;
+    const bool ok = nn < Nseq && t >= la;
+    const long bo = ok ? nn / Fo : 0, fo = ok ? nn % Fo : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = 8 * q + j;
+      float v = 0.f;
+      if (ok && o < O) v = dout[((bo * O + o) * Fo + fo) * To + (t - la)];
+      if constexpr (sizeof(T) == 2) a[j] = (__bf16)v; else a[j] = v;
+    }
+  }
+  for (int c0 = 0; c0 < Hd; c0 += 16) {
+    const int col = c0 + n < Hd ? c0 + n : Hd - 1;
+    const frag b = load_frag<T>(whT + (size_t)col * 32 + 8 * q);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mma16(a, b, acc);
+    if (c0 + n < Hd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long nn = n0 + 4 * q + j;
+        if (nn < Nseq) dh2[((size_t)t * Nseq + nn) * Hd + c0 + n] = from_f32<T>(acc[j]);
+      }
+    }
+  }
+}
+
+// dWh[o][u] += sum_rows dY[row][o] * h2[row][u];  dbh[o] += sum_rows dY[row][o]
+// block = (t, chunk of 64 rows); thread u (blockDim = Hd rounded up to 64)
+constexpr int HB_ROWS = 64;
+template <typename T>
+__global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __restrict__ h2, float* __restrict__ dWh,
+                                  float* __restrict__ dbh, long Nseq, int Tn, int la, int Hd, int O, int Fo) {
+  __shared__ float dy[HB_ROWS][33];
+  const int t = la + blockIdx.y;
+  const long n0 = (long)blockIdx.x * HB_ROWS;
+  const int To = Tn - la;
+  for (int e = threadIdx.x; e < HB_ROWS * 32; e += blockDim.x) {
+    const int r = e / 32, o = e % 32;
+    const long nn = n0 + r;
+    float v = 0.f;
+    if (nn < Nseq && o < O) {
+      const long bo = nn / Fo, fo = nn % Fo;
+      v = dout[((bo * O + o) * Fo + fo) * To + (t - la)];
+    }
+    dy[r][o] = v;
+  }
+  __syncthreads();
+  const int u = threadIdx.x;
+  if (u < Hd) {
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+    for (int r = 0; r < HB_ROWS; ++r) {
+      const long nn = n0 + r;
+      if (nn >= Nseq) break;
+      const float hv = to_f32<T>(h2[((size_t)t * Nseq + nn) * Hd + u]);
+#pragma unroll
+      for (int o = 0; o < 32; ++o) acc[o] += dy[r][o] * hv;
+    }
+#pragma unroll
+    for (int o = 0; o < 32; ++o)
+      if (o < O) atomicAdd(dWh + (size_t)o * Hd + u, acc[o]);
+  }
+  if (threadIdx.x < 32 && threadIdx.x < O) {
+    float s = 0.f;
+    for (int r = 0; r < HB_ROWS; ++r) s += dy[r][threadIdx.x];
+    atomicAdd(dbh + threadIdx.x, s);
+  }
+}
+
+// ---------------------------------------------------------------- sub-band staging backward
+// D[bo] = sum_{t, fo, j < nfeat} dx[t][n][j] * x[t][n][j]      (x = normalised LSTM input as staged)
+template <typename T>
+__global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const T* __restrict__ dx, const T* __restrict__ x,
+                                                            double* __restrict__ D, int Fo, int KX, int nfeat, long Nseq) {
+  __shared__ double red[4];
+  const int t = blockIdx.x, bo = blockIdx.y;
+  const size_t base = ((size_t)t * Nseq + (size_t)bo * Fo) * KX;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < Fo * KX; e += 256) {
+    if ((e % KX) < nfeat) s += to_f32<T>(dx[base + e]) * to_f32<T>(x[base + e]);
+  }
+  const double d = wave_sum((double)s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(D + bo, red[0] + red[1] + red[2] + red[3]);
+}
+
+// dpre[m][b][t][f] = (fb[m][b][t][f] > 0) * ( sc_b * (kept ? dx[t][n][W+m] : 0) - sc_b * D[bo] / Nn )
+template <typename T>
+__global__ __launch_bounds__(256) void sb_bwd_scatter_kernel(const T* __restrict__ dx, const T* __restrict__ fb,
+                                                             const float* __restrict__ scale, const double* __restrict__ D,
+                                                             T* __restrict__ dpre, int B, int F, int Tp, int ldF, long strideFb,
+                                                             int nb, int G, int Fo, int KX, long Nseq, double Nn) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  int g = 0, bo = b;
+  if (G > 1) {
+    g = b % G;
+    int start = 0;
+    for (int gg = 0; gg < g; ++gg) start += (B - gg + G - 1) / G;
+    bo = start + b / G;
+  }
+  const float sc = scale[b];
+  const float mterm = (float)((double)sc * D[bo] / Nn);
+  const int W = 2 * nb + 1;
+  const size_t row = (size_t)b * Tp + t;
+  for (int e = threadIdx.x; e < 3 * F; e += 256) {
+    const int m = e / F, f = e % F;
+    float gv = 0.f;
+    bool kept = true;
+    int fo = f;
+    if (G > 1) {
+      kept = (f % G) == g && f < Fo * G;
+      fo = f / G;
+    }
+    if (kept) gv = to_f32<T>(dx[((size_t)t * Nseq + (size_t)bo * Fo + fo) * KX + W + m]);
+    const size_t o = (size_t)m * strideFb + row * ldF + f;
+    const float v = to_f32<T>(fb[o]) > 0.f ? sc * gv - mterm : 0.f;
+    dpre[o] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------- slab reduction into parameter gradients
+// dst[map(r)][c] (+)= sum_s slabs[s][r][col0 + c],  r < rows, c < ncols
+// permH > 0: LSTM gate-row un-permutation, packed row r = u*4 + g' (i,g,f,o) -> torch row {0,2,1,3}[g']*permH + u
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long slab_stride, long ld, float* __restrict__ dst,
+                                    long dst_ld, int rows, int col0, int ncols, int permH, int accumulate, long sSlab,
+                                    long sDst) {
+  slabs += (size_t)blockIdx.z * sSlab;
+  dst += (size_t)blockIdx.z * sDst;
+  const long total = (long)rows * ncols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / ncols), c = (int)(e % ncols);
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slabs[(size_t)k * slab_stride + (size_t)r * ld + col0 + c];
+    int rr = r;
+    if (permH > 0) {
+      const int u = r >> 2, gp = r & 3;
+      const int tg = gp == 0 ? 0 : (gp == 1 ? 2 : (gp == 2 ? 1 : 3));
+      rr = tg * permH + u;
+    }
+    float* d = dst + (size_t)rr * dst_ld + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, no amsgrad)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                            float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long ld_in, long ld_out, long sIn, long sOut,
+                   int relu, int batch, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || batch <= 0) return NPPC_EBADARG;
+  dim3 grid(ceil_div(rows, 32), ceil_div(cols, 32), batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in,
+                       ld_out, sIn, sOut, relu);
+  else
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, rows, cols, ld_in, ld_out,
+                       sIn, sOut, relu);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
+                void* stream) {
+  if (!M || !out || rows <= 0 || cols <= 0) return NPPC_EBADARG;
+  const int rpb = 128;
+  dim3 grid(ceil_div(cols, 256), ceil_div(rows, rpb), batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, out, rows, cols, ld, sM, sOut, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)M, out, rows, cols, ld, sM, sOut, rpb);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h2, void* dh2, float* dWh, float* dbh,
+                     long Nseq, int Tn, int la, int Hd, int O, int Fo, void* stream) {
+  if (!dout || !whT || !h2 || !dh2 || !dWh || !dbh || O > 32 || O < 1 || Nseq % Fo) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long tiles = ((Nseq + 15) / 16) * Tn;
+  dim3 gw(ceil_div(Nseq, HB_ROWS), Tn - la);
+  const int bw = round_up(Hd, 64);
+  if (prec == NPPC_PREC_BF16) {
+    hipLaunchKernelGGL(head_bwd_dh_kernel<bf16_t>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const bf16_t*)whT,
+                       (bf16_t*)dh2, Nseq, Tn, la, Hd, O, Fo);
+    hipLaunchKernelGGL(head_bwd_w_kernel<bf16_t>, gw, dim3(bw), 0, s, dout, (const bf16_t*)h2, dWh, dbh, Nseq, Tn, la, Hd, O,
+                       Fo);
+  } else {
+    hipLaunchKernelGGL(head_bwd_dh_kernel<float>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const float*)whT,
+                       (float*)dh2, Nseq, Tn, la, Hd, O, Fo);
+    hipLaunchKernelGGL(head_bwd_w_kernel<float>, gw, dim3(bw), 0, s, dout, (const float*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_subband_stage_bwd(int prec, const void* dx, const void* x, const void* fb, const float* scale, double* D,
+                           void* dpre, int B, int F, int Tp, int Tv, int ldF, long strideFb, int nb, int G, int KX,
+                           void* stream) {
+  if (!dx || !x || !fb || !scale || !D || !dpre || B <= 0) return NPPC_EBADARG;
+  const int Geff = B > 1 ? G : 1;
+  const int Fo = Geff <= 1 ? F : (F - F % Geff) / Geff;
+  const long Nseq = (long)B * Fo;
+  const int nfeat = 2 * nb + 4;
+  const double Nn = (double)F * nfeat * Tv;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(D, 0, sizeof(double) * B, s) != hipSuccess) return NPPC_ELAUNCH;
+  dim3 grid(Tv, B);
+  if (prec == NPPC_PREC_BF16) {
+    hipLaunchKernelGGL(sb_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dx, (const bf16_t*)x, D, Fo, KX,
+                       nfeat, Nseq);
+    hipLaunchKernelGGL(sb_bwd_scatter_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dx, (const bf16_t*)fb, scale, D,
+                       (bf16_t*)dpre, B, F, Tp, ldF, strideFb, nb, Geff, Fo, KX, Nseq, Nn);
+  } else {
+    hipLaunchKernelGGL(sb_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)x, D, Fo, KX, nfeat,
+                       Nseq);
+    hipLaunchKernelGGL(sb_bwd_scatter_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)fb, scale, D,
+                       (float*)dpre, B, F, Tp, ldF, strideFb, nb, Geff, Fo, KX, Nseq, Nn);
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int col0,
+                      int ncols, int permH, int accumulate, long sSlab, long sDst, int batch, void* stream) {
+  if (!slabs || !dst || S < 1 || rows <= 0 || ncols <= 0) return NPPC_EBADARG;
+  const long total = (long)rows * ncols;
+  const int gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1, batch), dim3(256), 0, (hipStream_t)stream, slabs, S, slab_stride, ld,
+                     dst, dst_ld, rows, col0, ncols, permH, accumulate, sSlab, sDst);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                   double wd, int step, double gscale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return NPPC_EBADARG;
+  const double bc1 = 1.0 - pow(b1, (double)step);          // host fp64, like torch's python-side bias corrections
+  const double bc2s = sqrt(1.0 - pow(b2, (double)step));
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)b1, (float)b2,
+                     (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

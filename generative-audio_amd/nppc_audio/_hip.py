@@ -60,6 +60,7 @@ def dtype_of(prec):
 
 
 P, I, L, F = c_p, c_i, c_l, c_f
+D = ctypes.c_double
 PL = ctypes.POINTER(c_l)
 PI = ctypes.POINTER(c_i)
 
@@ -67,10 +68,10 @@ PI = ctypes.POINTER(c_i)
 SIGS = {
     "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
     "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
-    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
     "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
-    "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
     "nppc_stft": [P, P, P, P, I, I, I, I, P],
     "nppc_dropband": [P, P, I, I, I, I, I, P],
     "nppc_cirm_build_compress": [P, P, P, P, P, I, I, I, I, F, P],
@@ -78,7 +79,7 @@ SIGS = {
     "nppc_rowsum": [P, P, L, I, P],
     "nppc_tsse_fwd": [P, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
-    "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, P],
+    "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],
@@ -91,6 +92,16 @@ SIGS = {
     "nppc_gs_bwd_solve": [P, P, P, P, I, I, I, P],
     "nppc_loss_solve": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "nppc_loss_bwd_coef": [P, P, P, F, F, P, I, I, P],
+    "nppc_transpose": [I, P, P, I, I, L, L, L, L, I, I, P],
+    "nppc_colsum": [I, P, P, I, I, L, L, L, I, P],
+    "nppc_sb_head_bwd": [I, P, P, P, P, P, P, L, I, I, I, I, I, P],
+    "nppc_subband_stage_bwd": [I, P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, P],
+    "nppc_reduce_slabs": [P, I, L, L, P, L, I, I, I, I, I, L, L, I, P],
+    "nppc_adam_step": [P, P, P, P, L, D, D, D, D, D, I, D, P],
+    "nppc_tcn_gn_bwd": [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tcn_dwconv_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tsse_bwd": [I, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                      I, I, I, I, I, I, I, P],
 }
 _bound = set()
 

@@ -9,12 +9,12 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import PackedLSTM, lstm2_forward, pick_mtile
+from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, pick_mtile
 
 TCN_HIDDEN = 512
 TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
 BRANCHES = ("", "_real", "_imag")   # channel_attention{,_real,_imag} / fb_model{,_real,_imag}
-EPI_PLAIN, EPI_PRELU_STATS, EPI_RESIDUAL, EPI_RELU = 0, 1, 2, 3
+EPI_PLAIN, EPI_PRELU_STATS, EPI_RESIDUAL, EPI_RELU, EPI_PLAIN_F32, EPI_MASK_POS = 0, 1, 2, 3, 4, 5
 
 
 def rup(a, b):
@@ -111,6 +111,15 @@ class FSNEngine:
         self.Wfcp = torch.zeros(3, ldF, ldC, dtype=self.dt, device=self.dev)
         self.Opad = rup(self.O, 16)
         self.Whp = torch.zeros(self.Opad, self.Hd, dtype=self.dt, device=self.dev)
+        if trainable:
+            if self.O > 32:
+                raise NotImplementedError("n_directions <= 16 is what the head-backward kernel is built for")
+            self.lstm_bwd = PackedLSTMBwd(self.I, self.Hd, prec, self.dev)
+            self.W1T = torch.zeros(8, 3, ldC, TCN_HIDDEN, dtype=self.dt, device=self.dev)   # [c][k] = W1[k][c]
+            self.W2T = torch.zeros(8, 3, TCN_HIDDEN, ldC, dtype=self.dt, device=self.dev)   # [k][c] = W2[c][k]
+            self.WfcT = torch.zeros(3, ldC, ldF, dtype=self.dt, device=self.dev)            # [c][f] = Wfc[f][c]
+            self.WhT = torch.zeros(self.Hd, 32, dtype=self.dt, device=self.dev)             # [u][o] = Wh[o][u]
+            self.gbuf = [None, None]
 
     # ------------------------------------------------------------------ weights
     def p(self, name):
@@ -133,6 +142,20 @@ class FSNEngine:
                    ldF, ldC, 0, s)
         H.call("nppc_pack_matrix", self.prec, self.p("sb_model.fc_output_layer.weight"), self.Whp, self.O, self.Hd,
                self.Opad, self.Hd, 0, s)
+        if self.trainable:
+            for z, br in enumerate(BRANCHES):
+                for i in range(8):
+                    pre = f"fb_model{br}.sequence_model.{i}"
+                    H.call("nppc_pack_matrix", self.prec, self.p(pre + ".conv1x1.weight"), self.W1T[i, z], C, TCN_HIDDEN,
+                           ldC, TCN_HIDDEN, 1, s)
+                    H.call("nppc_pack_matrix", self.prec, self.p(pre + ".sconv.weight"), self.W2T[i, z], TCN_HIDDEN, C,
+                           TCN_HIDDEN, ldC, 1, s)
+                H.call("nppc_pack_matrix", self.prec, self.p(f"fb_model{br}.fc_output_layer.weight"), self.WfcT[z], C,
+                       self.F, ldC, ldF, 1, s)
+            H.call("nppc_pack_matrix", self.prec, self.p("sb_model.fc_output_layer.weight"), self.WhT, self.Hd, self.O,
+                   self.Hd, 32, 1, s)
+            q = "sb_model.sequence_model."
+            self.lstm_bwd.pack(*[self.p(q + n) for n in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")])
         q = "sb_model.sequence_model."
         self.lstm.pack(*[self.p(q + n) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
                                                   "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
@@ -189,6 +212,7 @@ class FSNEngine:
         C, ldC, ldF, sP = self.C, self.ldC, self.ldF, self.sP
         R = B * Tp
         maps = [m.contiguous().float() for m in maps]
+        d["maps"] = maps if train else None
         sv = d.get("tsse_saved")
         # 1-3: laplace norm + TSSE attention scale, transposed into the TCN input
         for z, br in enumerate(BRANCHES):
@@ -221,7 +245,7 @@ class FSNEngine:
             st1, st2 = d["stats"][i, 0], d["stats"][i, 1]
             H.call("nppc_gemm_nt", prec, EPI_PRELU_STATS, Xin, ldC, R * ldC, self.W1p[i], ldC, TCN_HIDDEN * ldC,
                    y1, TCN_HIDDEN, sAct, self.p(pre + "conv1x1.bias"), sP, None, 0, 0, self.p(pre + "prelu1.weight"), sP,
-                   st1, B * 2, R, TCN_HIDDEN, self.KC, Tp, Tv, TCN_HIDDEN, 0, 3, s)
+                   st1, B * 2, R, TCN_HIDDEN, self.KC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
             H.call("nppc_tcn_dwconv", prec, y1, y2, st1, st2, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
                    self.p(pre + "depthwise_conv.weight"), self.p(pre + "depthwise_conv.bias"),
                    self.p(pre + "prelu2.weight"), B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
@@ -229,12 +253,12 @@ class FSNEngine:
                    B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
             H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, d["a2"], TCN_HIDDEN, sAct, self.W2p[i], TCN_HIDDEN,
                    ldC * TCN_HIDDEN, Xout, ldC, R * ldC, self.p(pre + "sconv.bias"), sP, Xin, ldC, R * ldC, None, 0,
-                   None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, s)
+                   None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
         Xlast = d["X"][8 if train else 2]
         # 5: trailing ReLU + Linear(C -> F) + ReLU
         H.call("nppc_gemm_nt", prec, EPI_RELU, Xlast, ldC, R * ldC, self.Wfcp, ldC, ldF * ldC, d["fb"], ldF, R * ldF,
                self.p("fb_model.fc_output_layer.bias"), sP, None, 0, 0, None, 0, None, 0, R, ldF, self.KC, Tp, Tv, F, 1,
-               3, s)
+               3, 1, s)
         # 6: sub-band unfold + concat + norm + drop-band, staged time-major for the LSTM
         if self.nm == 1:
             src, ldS = d["X"][0, 0], ldC          # attention-scaled, normalised magnitude (fullsubnet_plus.py:203)
@@ -255,3 +279,164 @@ class FSNEngine:
                self.la, self.Hd, self.O, d["Fo"], s)
         self.last = d
         return out
+
+    # ------------------------------------------------------------------ backward (direction net)
+    def _grad_buffer(self):
+        """Flat gradient buffer that does NOT alias the parameters' current .grad (so autograd's accumulate
+        semantics stay right whether or not the caller cleared the grads)."""
+        first = self.fp.named[0][1]
+        for k in (0, 1):
+            if self.gbuf[k] is None:
+                self.gbuf[k] = torch.empty_like(self.fp.flat)
+            if first.grad is None or first.grad.data_ptr() != self.gbuf[k].data_ptr():
+                self.fp.grad = self.gbuf[k]
+                return self.gbuf[k]
+        raise RuntimeError("unreachable")
+
+    def g(self, name):
+        return self.fp.gview(name)
+
+    def _wgrad(self, AT, lda, sA, BT, ldb, sB, rows, ncolsN, K, S, dst_name_or_tensor, dst_ld, out_rows, ncols, slab,
+               batch=1, sDst=0, permH=0, col0=0, accumulate=0):
+        """dst[r][c] = sum_k AT[r][k] * BT[c][k]  via split-K fp32 slabs + reduction (one launch pair)."""
+        s = H.stream()
+        dst = self.g(dst_name_or_tensor) if isinstance(dst_name_or_tensor, str) else dst_name_or_tensor
+        H.call("nppc_gemm_nt", self.prec, EPI_PLAIN_F32, AT, lda, sA, BT, ldb, sB, slab, ncolsN, rows * ncolsN, None, 0,
+               None, 0, 0, None, 0, None, 0, rows, ncolsN, K, rows, rows, ncolsN, 0, batch, S, s)
+        H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, dst, dst_ld, out_rows, col0, ncols, permH, accumulate,
+               S * rows * ncolsN, sDst, batch, s)
+
+    def backward(self, dout):
+        """dout [B', O, F', T] fp32 -> flat parameter gradient (same layout as the flat parameter buffer)."""
+        d = self.last
+        assert "lstm" in d and "g1" in d["lstm"], "backward needs a forward(train=True)"
+        s = H.stream()
+        prec, dt, dev = self.prec, self.dt, self.dev
+        B, T, Tv, Tp = d["B"], d["T"], d["Tv"], d["Tp"]
+        F, C, ldC, ldF, sP, Hd, O = self.F, self.C, self.ldC, self.ldF, self.sP, self.Hd, self.O
+        R = B * Tp
+        Nseq, Fo = d["Nseq"], d["Fo"]
+        G = self._grad_buffer()
+        G.zero_()
+        lo = d["lstm"]
+        # ---- 1. head: dh2 = dY Wh, dWh, dbh
+        dh2 = torch.empty(Tv, Nseq, Hd, dtype=dt, device=dev)
+        H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
+               self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
+        # ---- 2. LSTM recurrence backward
+        dx, dg1T, dg2T = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
+        del dh2
+        # ---- 3. LSTM weight gradients: K-contiguous NT GEMMs on the transposed tensors
+        Np = padded_rows(Nseq)
+        Rp = Tv * Np
+        KXn = rup(self.KX, 64)
+        xT = torch.zeros(KXn, Rp, dtype=dt, device=dev)
+        H.call("nppc_transpose", prec, d["x_tm"], xT, Nseq, self.KX, self.KX, Rp, Nseq * self.KX, Np, 0, Tv, s)
+        xT[self.I].fill_(1.0)     # spare padded row = ones: its GEMM column is the bias gradient (sum over rows of dgates)
+        S = 1
+        while S < 32 and (Np // 32) % (2 * S) == 0:
+            S *= 2
+        K4 = 4 * Hd
+        K4p, HdN = dg1T.shape[0], lo["h1T"].shape[0]
+        slab = torch.empty(S * K4p * max(HdN, KXn), dtype=torch.float32, device=dev)
+        q = "sb_model.sequence_model."
+        I = self.I
+        self._wgrad(dg1T, Rp, 0, xT, Rp, 0, K4p, KXn, Rp, S, q + "weight_ih_l0", I, K4, I, slab, permH=Hd)
+        H.call("nppc_reduce_slabs", slab, S, K4p * KXn, KXn, self.g(q + "bias_ih_l0"), 1, K4, I, 1, Hd, 0, 0, 0, 1, s)
+        self.g(q + "bias_hh_l0").copy_(self.g(q + "bias_ih_l0"))
+        self._wgrad(dg2T, Rp, 0, xT, Rp, 0, K4p, KXn, Rp, S, self.g(q + "bias_ih_l1"), 1, K4, 1, slab, permH=Hd, col0=I)
+        self.g(q + "bias_hh_l1").copy_(self.g(q + "bias_ih_l1"))
+        self._wgrad(dg2T, Rp, 0, lo["h1T"], Rp, 0, K4p, HdN, Rp, S, q + "weight_ih_l1", Hd, K4, Hd, slab, permH=Hd)
+        if Tv > 1:
+            # h_{t-1}: the same transposed tensors, shifted by one time block (column offset Np)
+            self._wgrad(dg1T.view(-1)[Np:], Rp, 0, lo["h1T"], Rp, 0, K4p, HdN, Rp - Np, S, q + "weight_hh_l0", Hd, K4, Hd,
+                        slab, permH=Hd)
+            self._wgrad(dg2T.view(-1)[Np:], Rp, 0, lo["h2T"], Rp, 0, K4p, HdN, Rp - Np, S, q + "weight_hh_l1", Hd, K4, Hd,
+                        slab, permH=Hd)
+        del dg1T, dg2T, xT
+        # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
+        dpre_fb = torch.zeros(3, B, Tp, ldF, dtype=dt, device=dev)
+        Dsb = torch.empty(B, dtype=torch.float64, device=dev)
+        H.call("nppc_subband_stage_bwd", prec, dx, d["x_tm"], d["fb"], d["sbscale"], Dsb, dpre_fb, B, F, Tp, Tv, ldF, R * ldF,
+               self.nb, self.G, self.KX, s)
+        del dx
+        # ---- 5. fc_output_layer backward
+        S2 = 8 if R % (32 * 8) == 0 else 1
+        Fr = rup(F, 128)
+        Cr = rup(ldC, 128)
+        tA = torch.zeros(3, max(Cr, TCN_HIDDEN, Fr), R, dtype=dt, device=dev)       # transposed dY operand
+        tB = torch.zeros(3, max(ldC, TCN_HIDDEN), R, dtype=dt, device=dev)          # transposed activation operand
+        slab2 = torch.empty(3 * S2 * max(Cr * TCN_HIDDEN, TCN_HIDDEN * ldC, Fr * ldC), dtype=torch.float32, device=dev)
+        H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, s)
+        X8 = d["X"][8]
+        sTA, sTB = tA.shape[1] * R, tB.shape[1] * R
+        H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, s)
+        H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, s)
+        self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
+        dXa = torch.empty(3, B, Tp, ldC, dtype=dt, device=dev)
+        dXb = torch.empty(3, B, Tp, ldC, dtype=dt, device=dev)
+        H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
+               X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
+        del dpre_fb
+        # ---- 6. TCN blocks in reverse
+        sAct = B * Tp * TCN_HIDDEN
+        h1b = torch.empty(3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
+        h2b = torch.empty(3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
+        Sgn = torch.empty(3, B, 2, dtype=torch.float64, device=dev)
+        dXo, dXi = dXa, dXb
+        for i in range(7, -1, -1):
+            pre = f"fb_model.sequence_model.{i}."
+            dil = TCN_DILATIONS[i]
+            st1, st2 = d["stats"][i, 0], d["stats"][i, 1]
+            y1, y2, Xin = d["y1"][i], d["y2"][i], d["X"][i]
+            H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
+            # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
+            H.call("nppc_tcn_gn_apply", prec, y2, d["a2"], st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), B,
+                   TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
+            H.call("nppc_transpose", prec, dXo, tA, R, ldC, ldC, R, R * ldC, sTA, 0, 3, s)
+            H.call("nppc_transpose", prec, d["a2"], tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
+            self._wgrad(tA, R, sTA, tB, R, sTB, Cr, TCN_HIDDEN, R, S2, pre + "sconv.weight", TCN_HIDDEN, C, TCN_HIDDEN, slab2,
+                        batch=3, sDst=sP)
+            # dA2 = dXo W2
+            H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
+                   sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
+            # GroupNorm-2 + PReLU-2 backward
+            H.call("nppc_tcn_gn_bwd", prec, h1b, y2, st2, self.p(pre + "norm2.weight"), self.p(pre + "prelu2.weight"), Sgn, h2b,
+                   self.g(pre + "norm2.weight"), self.g(pre + "norm2.bias"), self.g(pre + "prelu2.weight"), B, TCN_HIDDEN, Tp,
+                   Tv, 1e-8, sAct, B * 2, sP, 3, s)
+            # depthwise conv backward (recomputes GN1(y1))
+            H.call("nppc_tcn_dwconv_bwd", prec, h2b, y1, st1, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
+                   self.p(pre + "depthwise_conv.weight"), h1b, self.g(pre + "depthwise_conv.weight"),
+                   self.g(pre + "depthwise_conv.bias"), B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
+            # GroupNorm-1 + PReLU-1 backward
+            H.call("nppc_tcn_gn_bwd", prec, h1b, y1, st1, self.p(pre + "norm1.weight"), self.p(pre + "prelu1.weight"), Sgn, h2b,
+                   self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"), self.g(pre + "prelu1.weight"), B, TCN_HIDDEN, Tp,
+                   Tv, 1e-8, sAct, B * 2, sP, 3, s)
+            # conv1x1: bias, weight, input gradients
+            H.call("nppc_colsum", prec, h2b, self.g(pre + "conv1x1.bias"), R, TCN_HIDDEN, TCN_HIDDEN, sAct, sP, 3, s)
+            H.call("nppc_transpose", prec, h2b, tA, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTA, 0, 3, s)
+            H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
+            self._wgrad(tA, R, sTA, tB, R, sTB, TCN_HIDDEN, ldC, R, S2, pre + "conv1x1.weight", C, TCN_HIDDEN, C, slab2, batch=3,
+                        sDst=sP)
+            H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
+                   R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
+            dXo, dXi = dXi, dXo
+        # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
+        sv = d["tsse_saved"]
+        dsg = torch.empty(B, F, dtype=torch.float32, device=dev)
+        maps = d["maps"]
+        for z, br in enumerate(BRANCHES):
+            att = f"channel_attention{br}."
+            for m in range(self.nm):
+                H.call("nppc_tsse_bwd", prec, dXo[z], maps[m * 3 + z], d["rs"][m * 3 + z],
+                       self.p(att + "smallConv1d.0.weight"), self.p(att + "middleConv1d.0.weight"),
+                       self.p(att + "largeConv1d.0.weight"), self.ks[0], self.ks[1], self.ks[2],
+                       self.p(att + "feature_concate_fc.weight"), self.p(att + "fc1.weight"), self.p(att + "fc2.weight"),
+                       sv["ns"][z, m], sv["pre"][z, m], sv["sq"][z, m], sv["h1"][z, m], sv["sg"][z, m], dsg,
+                       self.g(att + "smallConv1d.0.weight"), self.g(att + "smallConv1d.0.bias"),
+                       self.g(att + "middleConv1d.0.weight"), self.g(att + "middleConv1d.0.bias"),
+                       self.g(att + "largeConv1d.0.weight"), self.g(att + "largeConv1d.0.bias"),
+                       self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
+                       self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"),
+                       self.g(att + "fc2.bias"), B, F, T, self.la, Tp, ldC, m * F, s)
+        return G

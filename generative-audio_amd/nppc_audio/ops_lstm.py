@@ -36,16 +36,24 @@ def pick_mtile(n_seq, prec, train, n_cu=256):
     return 1
 
 
+def padded_rows(N):
+    """time-block stride of the transposed tensors: multiple of 32 so K-slices stay MFMA aligned"""
+    return (N + 31) // 32 * 32
+
+
 def lstm2_forward(x_tm, packed, train, mtile=None):
-    """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1, g1, g2, c1, c2]) time-major."""
+    """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1T, h2T, g1, g2, c1, c2]).
+    Transposed tensors are [rows][Tn*Np] with column t*Np + n (Np = padded_rows(N), padding zero)."""
     Tn, N, kx = x_tm.shape
+    Np = padded_rows(N)
     assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
     dt, dev = x_tm.dtype, x_tm.device
     out = {"h2": torch.empty(Tn, N, Hd, dtype=dt, device=dev)}
     if train:
-        out["h1T"] = torch.empty(Hd, Tn * N, dtype=dt, device=dev)
-        out["h2T"] = torch.empty(Hd, Tn * N, dtype=dt, device=dev)
+        Hr = (Hd + 63) // 64 * 64          # row padding so the tensors can be GEMM B-operands (N % 64 == 0)
+        out["h1T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
+        out["h2T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
         out["c1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
         out["c2"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
         out["g1"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
@@ -54,7 +62,7 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
         mtile = pick_mtile(N, packed.prec, train)
     H.call("nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
            out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn,
-           packed.I, Hd, H.stream())
+           packed.I, Hd, Np, H.stream())
     return out
 
 
@@ -80,9 +88,11 @@ def lstm2_backward(saved, dh2, packed_bwd, kx):
     (transposed gate gradients, row k = unit*4 + gate in (i,g,f,o) order)."""
     Tn, N, Hd = saved["h2"].shape
     dt, dev = dh2.dtype, dh2.device
+    Np = padded_rows(N)
     dx = torch.empty(Tn, N, kx, dtype=dt, device=dev)
-    dg1T = torch.empty(4 * Hd, Tn * N, dtype=dt, device=dev)
-    dg2T = torch.empty(4 * Hd, Tn * N, dtype=dt, device=dev)
+    Kr = (4 * Hd + 127) // 128 * 128   # row padding so the tensors can be GEMM A-operands (R % 128 == 0)
+    dg1T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
+    dg2T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
     H.call("nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
-           packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, H.stream())
+           packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream())
     return dx, dg1T, dg2T

@@ -26,7 +26,7 @@ int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, co
  * transposed hidden states h1T,h2T [H][Tn*N] that the weight-gradient GEMMs consume. */
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
                    const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
-                   int Tn, int I, int H, void* stream);
+                   int Tn, int I, int H, long Np, void* stream);
 
 #ifdef __cplusplus
 }
