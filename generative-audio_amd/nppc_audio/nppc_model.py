@@ -64,11 +64,12 @@ class NPPCModel(nn.Module):
         self._memo = None
 
     # -- shared front end ------------------------------------------------------------------------
-    def _front(self, noisy_waveform):
-        """STFT + frozen restorer, once per distinct input tensor."""
+    def _front(self, noisy_waveform, reuse=True):
+        """STFT + frozen restorer.  `forward` always recomputes (reuse=False) and leaves the result for the
+        `get_pred_crm` / gt-mask calls that follow on the SAME tensor within the step."""
         H.require_gpu()
         key = (noisy_waveform.data_ptr(), noisy_waveform._version, tuple(noisy_waveform.shape))
-        if self._memo is not None and self._memo[0] == key:
+        if reuse and self._memo is not None and self._memo[0] == key:
             return self._memo[1]
         st = self.config.stft_configuration
         if st.win_length != st.nfft:
@@ -82,7 +83,7 @@ class NPPCModel(nn.Module):
 
     def forward(self, noisy_waveform: torch.Tensor) -> torch.Tensor:
         """[B, L] -> w_mat [B, n_dirs, 2, F', T] (nppc_model.py:58-115)"""
-        f = self._front(noisy_waveform)
+        f = self._front(noisy_waveform, reuse=False)
         # decompress + the reference's swapped mask application (conj(mask) * noisy), utils.py:241-249
         _, emag, ere, eim = ops.cirm_decompress_apply_conj(f["pred_crm"], f["re"], f["im"])
         return self.audio_pc_wrapper(f["mag"][:, None], f["re"][:, None], f["im"][:, None],

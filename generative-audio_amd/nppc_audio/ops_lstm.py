@@ -6,6 +6,22 @@ import torch
 from . import _hip as H
 
 
+# bench.py sets this to a list to collect (label, start_event, end_event) around every LSTM launch; the events
+# are recorded on the current stream, i.e. the stream the kernels are enqueued on.
+PROFILE = None
+
+
+def _timed(label, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((label, e0, e1))
+    return r
+
+
 class PackedLSTM:
     """Per-wave MFMA B-fragment packing of nn.LSTM(I,Hd,2) weights (+ summed biases)."""
 
@@ -60,9 +76,10 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
         out["g2"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
-    H.call("nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
-           out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn,
-           packed.I, Hd, Np, H.stream())
+    _timed(("lstm2_fwd", int(train), N, Tn, mtile), lambda: H.call(
+        "nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
+        out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn,
+        packed.I, Hd, Np, H.stream()))
     return out
 
 
@@ -93,6 +110,7 @@ def lstm2_backward(saved, dh2, packed_bwd, kx):
     Kr = (4 * Hd + 127) // 128 * 128   # row padding so the tensors can be GEMM A-operands (R % 128 == 0)
     dg1T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
     dg2T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
-    H.call("nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
-           packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream())
+    _timed(("lstm2_bwd", 1, N, Tn, 1), lambda: H.call(
+        "nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
+        packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream()))
     return dx, dg1T, dg2T
