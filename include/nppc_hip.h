@@ -1,14 +1,16 @@
-/* C ABI of libnppc_hip.so -- the gfx950 kernels behind the NPPC-audio train step.
+/* C ABI of libnppc_hip.so -- the gfx950 (MI355X / CDNA4) kernels behind the NPPC-audio train step.
  *
- * The reference (kfirc1503/generative-audio) has no FFI: its hot path is stock PyTorch ops called
- * from Python.  Each entry point below replaces the ATen call sites cited
- * beside it (file:line under the reference root).  Conventions:
- *   - plain device pointers + sizes, no torch types; every tensor is borrowed for the launch,
- *     nothing is allocated or freed here; outputs/workspaces are pre-allocated by the caller
+ * The reference (kfirc1503/generative-audio) has no FFI: its hot path is stock PyTorch ops called from Python
+ * (SURVEY.md section 8b).  Each entry point below replaces the ATen call sites cited beside it (file:line under
+ * the reference root).  Conventions:
+ *   - plain device pointers + sizes, no torch types; every tensor is borrowed for the launch, nothing is
+ *     allocated or freed here; outputs / workspaces are pre-allocated by the caller
  *   - `stream` is a hipStream_t; launches are asynchronous and never synchronise the device
- *   - return 0 on success, non-zero (NPPC_E*) on bad arguments / unsupported shape / launch failure
- *   - prec: 0 = bf16 MFMA operands + bf16 saved activations, fp32 accumulate/state
+ *   - return 0 on success, non-zero on bad arguments (1) / launch failure (2) / unsupported shape (3)
+ *   - prec: 0 = bf16 MFMA operands + bf16 saved activations, fp32 accumulate / cell state / statistics
  *           1 = fp32 everywhere (exact-f32 MFMA) -- the parity mode
+ *   - activations of the full-band nets are time-major [batch][Tp][ld] (Tp = T' rounded up to 128, ld = channels
+ *     rounded up to 64, padding zero); sub-band tensors are time-major [T'][N][...], N = B*F' sequences
  */
 #ifndef NPPC_HIP_H
 #define NPPC_HIP_H
@@ -16,17 +18,115 @@
 extern "C" {
 #endif
 
-/* ---- sub-band sequence model: nn.LSTM(I,H,2) --------------------------------------------------
- * reference: audio_zen/model/module/sequence_model.py:30-37 (construction), :113-123 (forward) */
+/* ---- signal front end ------------------------------------------------------------------------------------
+ * torch.stft(center, periodic hann, onesided): utils.py:107-147, nppc_audio/trainer.py:349-355 */
+int nppc_stft(const float* wave, float* re, float* im, float* mag /*nullable*/, int B, int L, int nfft, int hop,
+              void* stream);
+/* drop_band: audio_zen/acoustics/feature.py:254-285 */
+int nppc_dropband(const float* in, float* out, int B, int C, int F, int T, int G, void* stream);
+/* build_complex_ideal_ratio_mask + compress_cIRM (+ drop_band of trainer.py:359-362): audio_zen/acoustics/mask.py:24-54 */
+int nppc_cirm_build_compress(const float* nr, const float* ni, const float* cr, const float* ci, float* out, int B, int F,
+                             int T, int G, float eps, void* stream);
+/* decompress_cIRM (mask.py:57-60) + crm_to_stft_components (utils.py:241-249 -> :75-79, conj(mask)*noisy) */
+int nppc_cirm_decompress_apply_conj(const float* crm, const float* nr, const float* ni, float* dec /*nullable*/,
+                                    float* emag, float* ere, float* eim, int B, int F, int T, void* stream);
+
+/* ---- full-band front: offline_laplace_norm + ChannelTimeSenseSELayer ---------------------------------------
+ * audio_zen/model/base_model.py:210-224, audio_zen/model/module/attention_model.py:43-98,
+ * fullsubnet_plus.py:158-185, nppc_audio/networks.py:80-112 */
+int nppc_rowsum(const float* x, double* sums, long R, int T, void* stream);
+int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const float* cb0, const float* cw1,
+                  const float* cb1, const float* cw2, const float* cb2, int ks0, int ks1, int ks2, const float* fcw,
+                  const float* fcb, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,
+                  float* ns, float* pre, float* sq, float* h1, float* sg, int B, int C, int T, int look_ahead,
+                  void* stream);
+int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsum, const float* cw0, const float* cw1,
+                  const float* cw2, int ks0, int ks1, int ks2, const float* fcw, const float* w1, const float* w2,
+                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws,
+                  float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1, float* g_cw2, float* g_cb2, float* g_fcw,
+                  float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int C, int T, int look_ahead, int Tp,
+                  int ld, int coff, void* stream);
+int nppc_scale_transpose(int prec, const float* x, const float* scale /*nullable*/, void* y, int B, int C, int T, int Tp,
+                         int ld, int coff, void* stream);
+
+/* ---- full-band TCN stack: TCNBlock x8 + Linear + ReLU ------------------------------------------------------
+ * audio_zen/model/module/causal_conv.py:67-108, audio_zen/model/module/sequence_model.py:47-58,106-112
+ * nppc_gemm_nt: C[R][N] = A[R][K] * B[N][K]^T (+ epilogue); epi: 0 plain, 1 bias+PReLU+GroupNorm statistics,
+ * 2 bias+residual, 3 bias+ReLU, 4 fp32 output (split-K slabs), 5 mask by (res > 0).  ksplit > 1 splits K. */
+int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                 long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
+                 long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
+                 int batch, int ksplit, void* stream);
+int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
+int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
+                    const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
+                    int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream);
+int nppc_tcn_gn_apply(int prec, const void* in, void* out, const double* st, const float* gamma, const float* beta, int B,
+                      int Cc, int ld, int Tp, int Tv, float eps, long sAct, long sSt, long sP, int batch, void* stream);
+/* backward of GroupNorm(1,C)+PReLU and of the depthwise dilated conv (autograd of causal_conv.py:96-108) */
+int nppc_tcn_gn_bwd(int prec, const void* dA, const void* y, const double* st, const float* gamma, const float* slope,
+                    double* S, void* dpre, float* dgamma, float* dbeta, float* dslope, int B, int Cc, int Tp, int Tv, float eps,
+                    long sAct, long sSt, long sP, int batch, void* stream);
+int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* st1, const float* gamma, const float* beta,
+                        const float* wd, void* dz, float* dwd, float* dbd, int B, int Cc, int Tp, int Tv, int dil, float eps,
+                        long sAct, long sSt, long sP, int batch, void* stream);
+int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long ld_in, long ld_out, long sIn, long sOut,
+                   int relu, int batch, void* stream);
+int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
+                void* stream);
+int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int col0,
+                      int ncols, int permH, int accumulate, long sSlab, long sDst, int batch, void* stream);
+
+/* ---- sub-band stage: unfold + concat + laplace norm + drop_band + LSTM input layout, output head ------------
+ * audio_zen/model/base_model.py:15-46, fullsubnet_plus.py:188-230, nppc_audio/networks.py:115-161,
+ * sequence_model.py:118-123 (fc_output_layer) */
+int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* mult,
+                      float* scale, int B, int F, int Tp, int Tv, int nfeat, void* stream);
+int nppc_subband_stage(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* scale,
+                       void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, void* stream);
+int nppc_subband_stage_bwd(int prec, const void* dx, const void* x, const void* fb, const float* scale, double* D,
+                           void* dpre, int B, int F, int Tp, int Tv, int ldF, long strideFb, int nb, int G, int KX,
+                           void* stream);
+int nppc_sb_head(int prec, const void* h2, const void* wh, const float* bias, float* out, long Nseq, int Tn, int la,
+                 int Hd, int O, int Fo, void* stream);
+int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h2, void* dh2, float* dWh, float* dbh,
+                     long Nseq, int Tn, int la, int Hd, int O, int Fo, void* stream);
+
+/* ---- sub-band sequence model: nn.LSTM(I,H,2) -----------------------------------------------------------------
+ * audio_zen/model/module/sequence_model.py:30-37 (construction), :113-123 (forward) and its autograd */
 int nppc_lstm2_packed_elems(int I, int H, long* n1, long* n2, int* kx);
 int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, const float* b_ih0, const float* b_hh0,
                             const float* w_ih1, const float* w_hh1, const float* b_ih1, const float* b_hh1, int I, int H,
                             void* wp1, void* wp2, float* bias1, float* bias2, void* stream);
 /* x [Tn][N][kx]; h2 [Tn][N][H] time-major; when train also c1,c2 [Tn][N][H], g1,g2 [Tn][N][H][4] (i,g,f,o) and the
- * transposed hidden states h1T,h2T [H][Tn*N] that the weight-gradient GEMMs consume. */
+ * transposed hidden states h1T,h2T [rows >= H][Tn*Np] (column of (t,n) = t*Np + n) for the weight-gradient GEMMs. */
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
                    const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
                    int Tn, int I, int H, long Np, void* stream);
+int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
+int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
+                                int I, int H, void* wb1, void* wb2, void* stream);
+/* dh2 [Tn][N][H] -> dx [Tn][N][kx], dg1T/dg2T [rows >= 4H][Tn*Np] (row k = unit*4 + gate in i,g,f,o order) */
+int nppc_lstm2_bwd(int prec, const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2,
+                   const void* wb1, const void* wb2, void* dx, void* dg1T, void* dg2T, long N, int Tn, int I, int H,
+                   long Np, void* stream);
+
+/* ---- Gram-Schmidt on the K complex directions + NPPC loss ----------------------------------------------------
+ * nppc_audio/pc_wrapper.py:8-44 (gram_schmidt_to_crm), nppc_audio/trainer.py:259-317 (base_step) */
+int nppc_gram(const float* a, const float* b_or_null, const float* gt, const float* pred, double* out, int B, int K,
+              long N, void* stream);
+int nppc_combine(const float* a, const double* M1, const float* b, const double* M2, const float* gt, const float* pred,
+                 float* out, int B, int K, long N, void* stream);
+int nppc_gs_solve(const double* G, double* C, double* Ch, int B, int K, int KV, void* stream);
+int nppc_gs_bwd_solve(const double* G, const double* P, const double* Ch, double* D, int B, int K, int KV, void* stream);
+int nppc_loss_solve(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
+                    float* reconst, float* sm, double* coefA, double* coefE, int B, int K, void* stream);
+int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* grec, float gobj_over_B, float gsm, double* M1,
+                       int B, int K, void* stream);
+
+/* ---- optimizer: torch.optim.Adam (nppc_audio/trainer.py:64-69,102-104) -------------------------------------- */
+int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                   double wd, int step, double gscale, void* stream);
 
 #ifdef __cplusplus
 }
