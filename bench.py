@@ -48,7 +48,9 @@ def build_trainer(precision, rank, world, batch, length):
         optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
         device="cuda")
     ds = SyntheticNoisySpeech(batch * world, length)
-    tr = NPPCAudioTrainer(cfg, dataset=ds)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the trainer prints like the reference; stdout is ONE JSON line
+        tr = NPPCAudioTrainer(cfg, dataset=ds)
     dev = torch.device("cuda", torch.cuda.current_device())
     # this rank's shard of the (single) global minibatch, uploaded once: inputs are HBM-resident for the timed region
     clips = [ds[rank * batch + i] for i in range(batch)]

@@ -78,6 +78,17 @@ template <> __device__ __forceinline__ void store_pair<bf16_t>(bf16_t* p, float 
   *reinterpret_cast<uint32_t*>(p) = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
 }
 
+template <typename T> __device__ __forceinline__ void store_gates(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_gates<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store_gates<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  v.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+
 // One LSTM layer step for this wave's 16*UB units x M rows.  Two passes over K keep only two gate
 // accumulators live: pass 0 -> i,g (ig = sigmoid(i)*tanh(g)), pass 1 -> f,o -> c, h.
 // Saved gate layout per (t,row,unit): [i, g, f, o] (post-activation).
@@ -501,20 +512,58 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
   const T* a_lane = Abuf + n * RSA + 8 * q;
   __syncthreads();
 
-  // cell backward for this thread's (row, units); dh_tot comes from LDS (+ the external grad for layer 2)
-  auto cell_bwd = [&](const T* gs, const T* cs, const float* dh_lds, const T* dh_ext, float (&dc)[UPT], int t) {
+  // Saved state of one (layer, step) for this thread's (row, UPT units), fetched one phase AHEAD (during the previous
+  // GEMM) so the cell-backward phase never waits on HBM.
+  struct Saved {
+    T g[UPT * 4];   // i,g,f,o per unit
+    T ct[UPT];
+    T cp[UPT];
+    T dh[UPT];      // external gradient into h (layer 2 only)
+  };
+  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t) {
+    if (!prow_ok || t < 0) return;
     const size_t e = ((size_t)t * N + row0 + prow) * H + u0;
-    const size_t ep = ((size_t)(t - 1) * N + row0 + prow) * H + u0;
+    constexpr int GB = UPT * 4 * (int)sizeof(T), CB = UPT * (int)sizeof(T);
+    const char* gp = reinterpret_cast<const char*>(gs + e * 4);
+    const char* cp_ = reinterpret_cast<const char*>(cs + e);
+    if constexpr (GB % 16 == 0 && CB % 8 == 0) {
+#pragma unroll
+      for (int i = 0; i < GB / 16; ++i) reinterpret_cast<uint4*>(sv.g)[i] = reinterpret_cast<const uint4*>(gp)[i];
+#pragma unroll
+      for (int i = 0; i < CB / 8; ++i) reinterpret_cast<uint2*>(sv.ct)[i] = reinterpret_cast<const uint2*>(cp_)[i];
+      if (t > 0) {
+        const char* pp = reinterpret_cast<const char*>(cs + e - (size_t)N * H);
+#pragma unroll
+        for (int i = 0; i < CB / 8; ++i) reinterpret_cast<uint2*>(sv.cp)[i] = reinterpret_cast<const uint2*>(pp)[i];
+      }
+      if (dh_ext) {
+        const char* dp = reinterpret_cast<const char*>(dh_ext + e);
+#pragma unroll
+        for (int i = 0; i < CB / 8; ++i) reinterpret_cast<uint2*>(sv.dh)[i] = reinterpret_cast<const uint2*>(dp)[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < UPT * 4; ++i) sv.g[i] = gs[e * 4 + i];
+#pragma unroll
+      for (int i = 0; i < UPT; ++i) {
+        sv.ct[i] = cs[e + i];
+        if (t > 0) sv.cp[i] = cs[e - (size_t)N * H + i];
+        if (dh_ext) sv.dh[i] = dh_ext[e + i];
+      }
+    }
+  };
+  // cell backward for this thread's (row, units); dh_tot comes from LDS (+ the external grad for layer 2)
+  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float (&dc)[UPT], int t) {
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       float di = 0.f, dg = 0.f, df = 0.f, dO = 0.f;
       if (prow_ok) {
-        const float iv = to_f32<T>(gs[(e + i) * 4 + 0]), gv = to_f32<T>(gs[(e + i) * 4 + 1]);
-        const float fv = to_f32<T>(gs[(e + i) * 4 + 2]), ov = to_f32<T>(gs[(e + i) * 4 + 3]);
-        const float ct = to_f32<T>(cs[e + i]);
-        const float cp = t > 0 ? to_f32<T>(cs[ep + i]) : 0.f;
+        const float iv = to_f32<T>(sv.g[i * 4 + 0]), gv = to_f32<T>(sv.g[i * 4 + 1]);
+        const float fv = to_f32<T>(sv.g[i * 4 + 2]), ov = to_f32<T>(sv.g[i * 4 + 3]);
+        const float ct = to_f32<T>(sv.ct[i]);
+        const float cp = t > 0 ? to_f32<T>(sv.cp[i]) : 0.f;
         float dh = dh_lds[prow * HP + u0 + i];
-        if (dh_ext) dh += to_f32<T>(dh_ext[e + i]);
+        if (has_ext) dh += to_f32<T>(sv.dh[i]);
         const float tc = tanh_f(ct);
         const float dct = dh * ov * (1.f - tc * tc) + dc[i];
         dO = dh * tc * ov * (1.f - ov);
@@ -524,28 +573,37 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
         dc[i] = dct * fv;
       }
       T* ap = Abuf + prow * RSA + (u0 + i) * 4;
-      ap[0] = from_f32<T>(di);
-      ap[1] = from_f32<T>(dg);
-      ap[2] = from_f32<T>(df);
-      ap[3] = from_f32<T>(dO);
+      store_gates<T>(ap, di, dg, df, dO);
     }
   };
-  // transposed copy of the dgates tile: dgT[k][t*N + row0 + r], r < 16
+  // transposed copy of the dgates tile: dgT[k][t*Np + row0 + r], r < 16  (16 rows = one 32/64-byte run per k)
   auto write_T = [&](T* dgT, int t) {
     const size_t cbase = (size_t)t * a.Np + row0;
+    const bool full = row0 + M <= N;
     for (int k = tid; k < K4; k += NT) {
       T* dst = dgT + (size_t)k * R + cbase;
+      T v[M];
 #pragma unroll
-      for (int r = 0; r < M; ++r)
-        if (row0 + r < N) dst[r] = Abuf[r * RSA + k];
+      for (int r = 0; r < M; ++r) v[r] = Abuf[r * RSA + k];
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < M * (int)sizeof(T) / 16; ++i) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(v)[i];
+      } else {
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+          if (row0 + r < N) dst[r] = v[r];
+      }
     }
   };
 
+  Saved sv2, sv1;
+  fetch(sv2, g2, c2, dh2, a.Tn - 1);
 #pragma unroll 1
   for (int t = a.Tn - 1; t >= 0; --t) {
     // ---- layer 2
-    cell_bwd(g2, c2, dhrec2, dh2, dc2, t);
+    cell_bwd(sv2, dhrec2, true, dc2, t);
     __syncthreads();
+    fetch(sv1, g1, c1, nullptr, t);          // layer-1 state of this step: lands during the layer-2 GEMM
     {
       f32x4 acc[TPW2];
 #pragma unroll
@@ -567,8 +625,9 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
     }
     __syncthreads();
     // ---- layer 1
-    cell_bwd(g1, c1, dh1buf, nullptr, dc1, t);
+    cell_bwd(sv1, dh1buf, false, dc1, t);
     __syncthreads();
+    fetch(sv2, g2, c2, dh2, t - 1);          // layer-2 state of the next (earlier) step: lands during the layer-1 GEMM
     {
       f32x4 acc[TPW1];
 #pragma unroll

@@ -359,3 +359,130 @@ int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Np
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// LDS-staged NT GEMM for the long-K weight-gradient products (K = T'*N ~ 1e6, split over blockIdx.z):
+//   C_slab[z][M][N] (fp32) = A[M][Kz] * B[N][Kz]^T,   A, B K-contiguous.
+// 256 threads = 2x2 waves, block tile 128x128, 128-byte K slices per stage (64 bf16 / 32 f32), double-buffered LDS,
+// register staging (issue the next stage's global loads before the MFMAs, write them to LDS after), one barrier
+// per stage.  LDS rows are 128 B = 8 chunks of 16 B stored at slot (chunk ^ (row & 7)): both the staging
+// ds_write_b128 and the fragment ds_read_b128 are bank-conflict free.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_tiled_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B,
+                                                               long ldb, float* __restrict__ C, long ldc, long slab_stride,
+                                                               long Kz) {
+  typedef typename Frag<T>::type frag;
+  constexpr int EPC = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;                   // elements per 128-byte stage row
+  constexpr int KS = BK / 32;                   // 32-wide MFMA k-steps per stage
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * 128];   // [buffer][A|B][row*128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * 128, n0 = (long)blockIdx.y * 128;
+  const long kbase = (long)blockIdx.z * Kz;
+  const T* Ab = A + m0 * lda + kbase;
+  const T* Bb = B + n0 * ldb + kbase;
+  float* Cz = C + (size_t)blockIdx.z * slab_stride;
+
+  // per-thread staging slots: chunk (row, c) of the 128 x 8-chunk stage, i = 0..3
+  const int srow = tid >> 3, sc = tid & 7;                       // rows srow + 32*i
+  const T* ga = Ab + (long)srow * lda + sc * EPC;
+  const T* gb = Bb + (long)srow * ldb + sc * EPC;
+  const int soff = srow * 128 + ((sc ^ (srow & 7)) << 4);        // (srow + 32*i) & 7 == srow & 7
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GLOAD(k0)                                                              \
+  ra0 = *reinterpret_cast<const uint4*>(ga + (k0));                            \
+  ra1 = *reinterpret_cast<const uint4*>(ga + 32 * lda + (k0));                 \
+  ra2 = *reinterpret_cast<const uint4*>(ga + 64 * lda + (k0));                 \
+  ra3 = *reinterpret_cast<const uint4*>(ga + 96 * lda + (k0));                 \
+  rb0 = *reinterpret_cast<const uint4*>(gb + (k0));                            \
+  rb1 = *reinterpret_cast<const uint4*>(gb + 32 * ldb + (k0));                 \
+  rb2 = *reinterpret_cast<const uint4*>(gb + 64 * ldb + (k0));                 \
+  rb3 = *reinterpret_cast<const uint4*>(gb + 96 * ldb + (k0));
+#define LSTORE(buf)                                                            \
+  *reinterpret_cast<uint4*>(&lds[buf][0][soff]) = ra0;                         \
+  *reinterpret_cast<uint4*>(&lds[buf][0][soff + 32 * 128]) = ra1;              \
+  *reinterpret_cast<uint4*>(&lds[buf][0][soff + 64 * 128]) = ra2;              \
+  *reinterpret_cast<uint4*>(&lds[buf][0][soff + 96 * 128]) = ra3;              \
+  *reinterpret_cast<uint4*>(&lds[buf][1][soff]) = rb0;                         \
+  *reinterpret_cast<uint4*>(&lds[buf][1][soff + 32 * 128]) = rb1;              \
+  *reinterpret_cast<uint4*>(&lds[buf][1][soff + 64 * 128]) = rb2;              \
+  *reinterpret_cast<uint4*>(&lds[buf][1][soff + 96 * 128]) = rb3;
+  auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
+    if constexpr (sizeof(T) == 2) {
+      const int c = 4 * ks + q;
+      return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+      const int c0 = 2 * q, c1 = 2 * q + 1;   // KS == 1: the 32-float row is the whole k-step
+      const float4 lo = *reinterpret_cast<const float4*>(base + row * 128 + ((c0 ^ (row & 7)) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(base + row * 128 + ((c1 ^ (row & 7)) << 4));
+      frag f;
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+      return f;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long nstage = Kz / BK;
+  GLOAD(0)
+  LSTORE(0)
+  __syncthreads();
+  for (long s = 0; s < nstage; ++s) {
+    const int buf = (int)(s & 1);
+    if (s + 1 < nstage) { GLOAD((s + 1) * BK) }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      frag af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lfrag(lds[buf][0], wm * 64 + 16 * i + n, ks);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = lfrag(lds[buf][1], wn * 64 + 16 * j + n, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma16(af[i], bf[j], acc[i][j]);
+    }
+    if (s + 1 < nstage) { LSTORE(buf ^ 1) }
+    __syncthreads();
+  }
+#undef GLOAD
+#undef LSTORE
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + 16 * i + 4 * q + r;
+        const long col = n0 + wn * 64 + 16 * j + n;
+        Cz[row * ldc + col] = acc[i][j][r];
+      }
+}
+
+}  // namespace
+
+extern "C" int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N,
+                                   long K, int ksplit, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return NPPC_EBADARG;
+  const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
+  if (M % 128 || N % 128 || K % ((long)bk * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
+  dim3 grid(M / 128, N / 128, ksplit);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(gemm_nt_tiled_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
+                       (long)M * ldc, K / ksplit);
+  else if (prec == NPPC_PREC_F32)
+    hipLaunchKernelGGL(gemm_nt_tiled_kernel<float>, grid, dim3(256), 0, s, (const float*)A, lda, (const float*)B, ldb, C, ldc,
+                       (long)M * ldc, K / ksplit);
+  else
+    return NPPC_EBADARG;
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}

@@ -301,8 +301,12 @@ class FSNEngine:
         """dst[r][c] = sum_k AT[r][k] * BT[c][k]  via split-K fp32 slabs + reduction (one launch pair)."""
         s = H.stream()
         dst = self.g(dst_name_or_tensor) if isinstance(dst_name_or_tensor, str) else dst_name_or_tensor
-        H.call("nppc_gemm_nt", self.prec, EPI_PLAIN_F32, AT, lda, sA, BT, ldb, sB, slab, ncolsN, rows * ncolsN, None, 0,
-               None, 0, 0, None, 0, None, 0, rows, ncolsN, K, rows, rows, ncolsN, 0, batch, S, s)
+        bk = 64 if self.prec == H.PREC_BF16 else 32
+        if batch == 1 and rows % 128 == 0 and ncolsN % 128 == 0 and K % (bk * S) == 0:
+            H.call("nppc_gemm_nt_splitk", self.prec, AT, lda, BT, ldb, slab, ncolsN, rows, ncolsN, K, S, s)
+        else:
+            H.call("nppc_gemm_nt", self.prec, EPI_PLAIN_F32, AT, lda, sA, BT, ldb, sB, slab, ncolsN, rows * ncolsN, None,
+                   0, None, 0, 0, None, 0, None, 0, rows, ncolsN, K, rows, rows, ncolsN, 0, batch, S, s)
         H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, dst, dst_ld, out_rows, col0, ncols, permH, accumulate,
                S * rows * ncolsN, sDst, batch, s)
 
@@ -329,12 +333,12 @@ class FSNEngine:
         # ---- 3. LSTM weight gradients: K-contiguous NT GEMMs on the transposed tensors
         Np = padded_rows(Nseq)
         Rp = Tv * Np
-        KXn = rup(self.KX, 64)
+        KXn = rup(self.KX, 128)
         xT = torch.zeros(KXn, Rp, dtype=dt, device=dev)
         H.call("nppc_transpose", prec, d["x_tm"], xT, Nseq, self.KX, self.KX, Rp, Nseq * self.KX, Np, 0, Tv, s)
         xT[self.I].fill_(1.0)     # spare padded row = ones: its GEMM column is the bias gradient (sum over rows of dgates)
         S = 1
-        while S < 32 and (Np // 32) % (2 * S) == 0:
+        while S < 16 and (Np // 64) % (2 * S) == 0 and Np % 64 == 0:
             S *= 2
         K4 = 4 * Hd
         K4p, HdN = dg1T.shape[0], lo["h1T"].shape[0]

@@ -67,7 +67,7 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
     dt, dev = x_tm.dtype, x_tm.device
     out = {"h2": torch.empty(Tn, N, Hd, dtype=dt, device=dev)}
     if train:
-        Hr = (Hd + 63) // 64 * 64          # row padding so the tensors can be GEMM B-operands (N % 64 == 0)
+        Hr = (Hd + 127) // 128 * 128       # row padding so the tensors can be GEMM B-operands (N % 128 == 0)
         out["h1T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
         out["h2T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
         out["c1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)

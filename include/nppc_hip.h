@@ -57,6 +57,10 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
                  long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
                  long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
                  int batch, int ksplit, void* stream);
+/* long-K weight-gradient product: C_slab[z][M][N] (fp32) = A[M][K/ksplit slice z] * B[N][same slice]^T, LDS-staged
+ * 128x128 tiles; M, N multiples of 128, K a multiple of (64 bf16 | 32 fp32) * ksplit */
+int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long K,
+                        int ksplit, void* stream);
 int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
 int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
                     const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
