@@ -36,7 +36,7 @@ struct LstmFwdArgs {
 // One gate PAIR (gp = 0: i,g   gp = 1: f,o) of one layer:  acc[ub][s][mt] += A[16mt.., koff..] * Wpair
 // A is one contiguous K range of the LDS row (see the layout in lstm2_fwd_kernel).
 // Packed B fragments of this wave/pair: w_lane + (kk*UB*2 + ub*2 + s)*512.  nk is even.
-template <typename T, int UB, int MT, int RS>
+template <typename T, int UB, int MT, int RS, int DEPTH>
 __device__ __forceinline__ void pair_gemm(f32x4 (&acc)[UB][2][MT], const T* a_lane, int nk, __amdgpu_buffer_rsrc_t wr,
                                           int wave_boff /*uniform byte offset of this wave's (pair) stream*/, int lane) {
   typedef typename Frag<T>::type frag;
@@ -56,18 +56,21 @@ __device__ __forceinline__ void pair_gemm(f32x4 (&acc)[UB][2][MT], const T* a_la
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[ub][s][mt] = mma16(af[mt], b[ub * 2 + s], acc[ub][s][mt]);
   };
-  frag b0[UB * 2], b1[UB * 2];
-  loadb(b0, 0);
+  // DEPTH-stage register ring: DEPTH-1 k-steps of weight fragments are in flight while one is consumed.  The stream
+  // is bound by how many bytes a CU keeps in flight towards L2, so depth (not issue rate) sets the speed.
+  frag b[DEPTH][UB * 2];
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if (d < nk) loadb(b[d], d);
 #pragma unroll 1
-  for (int kk = 0; kk < nk - 2; kk += 2) {
-    loadb(b1, kk + 1);
-    compute(b0, kk);
-    loadb(b0, kk + 2);
-    compute(b1, kk + 1);
+  for (int kk = 0; kk < nk; kk += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int kl = kk + d + DEPTH - 1;
+      if (kl < nk) loadb(b[(d + DEPTH - 1) % DEPTH], kl);
+      if (kk + d < nk) compute(b[d], kk + d);
+    }
   }
-  loadb(b1, nk - 1);
-  compute(b0, nk - 2);
-  compute(b1, nk - 1);
 }
 
 template <typename T> __device__ __forceinline__ void store_pair(T* p, float a, float b);
@@ -94,13 +97,14 @@ template <> __device__ __forceinline__ void store_gates<bf16_t>(bf16_t* p, float
 // Saved gate layout per (t,row,unit): [i, g, f, o] (post-activation).
 // Addressing: element (row 16mt+4q+j, unit ubase+16ub+n) = ebase + (16mt+j)*H + 16ub with
 // ebase = (t*N + row0 + 4q)*H + ubase + n, so every per-element offset is a compile-time constant.
-template <typename T, int UB, int MT, int RS, int H, bool SAVE, bool WRITE_H>
+template <typename T, int UB, int MT, int RS, int H, bool SAVE, bool WRITE_H, int DEPTH>
 __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c)[UB][MT], const T* a_lane, int nk,
                                            __amdgpu_buffer_rsrc_t wr, int wave_boff, int pair_bstride, int lane,
                                            T* lds_h /* + 4q*RS + ubase+n */,
                                            long rbase /* row0 + 4q */, long N, size_t ebase, T* gates_out, T* c_out,
                                            T* h_out, T* hT_out /* + unit*R + t*N + rbase */, size_t R) {
   f32x4 ig[UB][MT];
+  f32x4 sv_i[SAVE ? UB : 1][SAVE ? MT : 1], sv_g[SAVE ? UB : 1][SAVE ? MT : 1];   // post-activation i, g kept for one store
   {
     f32x4 acc[UB][2][MT];
 #pragma unroll
@@ -109,7 +113,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
       for (int mt = 0; mt < MT; ++mt) {
         acc[ub][0][mt] = acc[ub][1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    pair_gemm<T, UB, MT, RS>(acc, a_lane, nk, wr, wave_boff, lane);
+    pair_gemm<T, UB, MT, RS, DEPTH>(acc, a_lane, nk, wr, wave_boff, lane);
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -120,7 +124,8 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
           const float gv = tanh_f(acc[ub][1][mt][j] + bias[ub][2]);
           ig[ub][mt][j] = iv * gv;
           if (SAVE) {
-            if (rbase + 16 * mt + j < N) store_pair<T>(gates_out + (ebase + (16 * mt + j) * H + 16 * ub) * 4, iv, gv);
+            sv_i[ub][mt][j] = iv;
+            sv_g[ub][mt][j] = gv;
           }
         }
   }
@@ -131,7 +136,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
     for (int mt = 0; mt < MT; ++mt) {
       acc[ub][0][mt] = acc[ub][1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  pair_gemm<T, UB, MT, RS>(acc, a_lane, nk, wr, wave_boff + pair_bstride, lane);
+  pair_gemm<T, UB, MT, RS, DEPTH>(acc, a_lane, nk, wr, wave_boff + pair_bstride, lane);
 #pragma unroll
   for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
@@ -149,7 +154,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
           if (WRITE_H) h_out[e] = from_f32<T>(hn);
           if (SAVE) {
             c_out[e] = from_f32<T>(cn);
-            store_pair<T>(gates_out + e * 4 + 2, fv, ov);
+            store_gates<T>(gates_out + e * 4, sv_i[ub][mt][j], sv_g[ub][mt][j], fv, ov);
             hT_out[(size_t)(16 * ub) * R + 16 * mt + j] = from_f32<T>(hn);   // rows j = 0..3 are adjacent: 4 x T per lane
           }
         }
@@ -209,7 +214,8 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
   __syncthreads();
 
   constexpr int nk1 = (KX + HP) / 32, nk2 = 2 * HP / 32;
-  static_assert(nk1 % 2 == 0 && nk2 % 2 == 0, "pair_gemm is unrolled by two k-steps");
+  // weight-fragment prefetch depth: as deep as the register budget of the variant allows
+  constexpr int DEPTH = (sizeof(T) == 2 && MT == 1) ? 4 : 2;
   constexpr int ps1 = NW * nk1 * UB * 2 * 512 * (int)sizeof(T);  // gate-pair stride (bytes)
   constexpr int ps2 = NW * nk2 * UB * 2 * 512 * (int)sizeof(T);
   const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wp1, 2u * ps1);
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
     }
     // layer 1: [x_t | h1_{t-1}]  ->  h1_t into the other half
     const size_t tbase = (size_t)ubase_n * Rtot + (size_t)t * a.Np + rbase;
-    layer_step<T, UB, MT, RS, H, TRAIN, false>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
+    layer_step<T, UB, MT, RS, H, TRAIN, false, DEPTH>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
                                                g1o, c1o, nullptr, TRAIN ? h1T + tbase : nullptr, Rtot);
     if (more) {
 #pragma unroll
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
     }
     __syncthreads();
     // layer 2: [h1_t | h2_{t-1}] (other half)  ->  h2_t into this half
-    layer_step<T, UB, MT, RS, H, TRAIN, true>(b2, c2, a_lane + oth + KX, nk2, wr2, wb2, ps2, lane, hw_lane + cur + KX + HP, rbase, N,
+    layer_step<T, UB, MT, RS, H, TRAIN, true, DEPTH>(b2, c2, a_lane + oth + KX, nk2, wr2, wb2, ps2, lane, hw_lane + cur + KX + HP, rbase, N,
                                               ebase, g2o, c2o, h2o, TRAIN ? h2T + tbase : nullptr, Rtot);
     // One barrier per step suffices: what step t+1 writes before its barrier (h1 -> half_p.H1,
     // x_{t+2} -> half_p.X, and after it h2 -> half_{1-p}.H2) was last READ before the barrier above

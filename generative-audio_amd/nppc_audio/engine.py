@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, pick_mtile
+from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, pick_mtile, workspace
 
 TCN_HIDDEN = 512
 TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
@@ -324,17 +324,17 @@ class FSNEngine:
         G.zero_()
         lo = d["lstm"]
         # ---- 1. head: dh2 = dY Wh, dWh, dbh
-        dh2 = torch.empty(Tv, Nseq, Hd, dtype=dt, device=dev)
+        ws = lambda name, shape, dtype=dt, zero=False: workspace(("eng", id(self), name), shape, dtype, dev, zero)
+        dh2 = ws("dh2", (Tv, Nseq, Hd))
         H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
                self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
         # ---- 2. LSTM recurrence backward
         dx, dg1T, dg2T = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
-        del dh2
         # ---- 3. LSTM weight gradients: K-contiguous NT GEMMs on the transposed tensors
         Np = padded_rows(Nseq)
         Rp = Tv * Np
         KXn = rup(self.KX, 128)
-        xT = torch.zeros(KXn, Rp, dtype=dt, device=dev)
+        xT = ws("xT", (KXn, Rp), zero=True)
         H.call("nppc_transpose", prec, d["x_tm"], xT, Nseq, self.KX, self.KX, Rp, Nseq * self.KX, Np, 0, Tv, s)
         xT[self.I].fill_(1.0)     # spare padded row = ones: its GEMM column is the bias gradient (sum over rows of dgates)
         S = 1
@@ -342,7 +342,7 @@ class FSNEngine:
             S *= 2
         K4 = 4 * Hd
         K4p, HdN = dg1T.shape[0], lo["h1T"].shape[0]
-        slab = torch.empty(S * K4p * max(HdN, KXn), dtype=torch.float32, device=dev)
+        slab = ws("slab", (S * K4p * max(HdN, KXn),), torch.float32)
         q = "sb_model.sequence_model."
         I = self.I
         self._wgrad(dg1T, Rp, 0, xT, Rp, 0, K4p, KXn, Rp, S, q + "weight_ih_l0", I, K4, I, slab, permH=Hd)
@@ -357,36 +357,33 @@ class FSNEngine:
                         slab, permH=Hd)
             self._wgrad(dg2T.view(-1)[Np:], Rp, 0, lo["h2T"], Rp, 0, K4p, HdN, Rp - Np, S, q + "weight_hh_l1", Hd, K4, Hd,
                         slab, permH=Hd)
-        del dg1T, dg2T, xT
         # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
-        dpre_fb = torch.zeros(3, B, Tp, ldF, dtype=dt, device=dev)
-        Dsb = torch.empty(B, dtype=torch.float64, device=dev)
+        dpre_fb = ws("dpre_fb", (3, B, Tp, ldF), zero=True)
+        Dsb = ws("Dsb", (B,), torch.float64)
         H.call("nppc_subband_stage_bwd", prec, dx, d["x_tm"], d["fb"], d["sbscale"], Dsb, dpre_fb, B, F, Tp, Tv, ldF, R * ldF,
                self.nb, self.G, self.KX, s)
-        del dx
         # ---- 5. fc_output_layer backward
         S2 = 8 if R % (32 * 8) == 0 else 1
         Fr = rup(F, 128)
         Cr = rup(ldC, 128)
-        tA = torch.zeros(3, max(Cr, TCN_HIDDEN, Fr), R, dtype=dt, device=dev)       # transposed dY operand
-        tB = torch.zeros(3, max(ldC, TCN_HIDDEN), R, dtype=dt, device=dev)          # transposed activation operand
-        slab2 = torch.empty(3 * S2 * max(Cr * TCN_HIDDEN, TCN_HIDDEN * ldC, Fr * ldC), dtype=torch.float32, device=dev)
+        tA = ws("tA", (3, max(Cr, TCN_HIDDEN, Fr), R), zero=True)       # transposed dY operand
+        tB = ws("tB", (3, max(ldC, TCN_HIDDEN), R), zero=True)          # transposed activation operand
+        slab2 = ws("slab2", (3 * S2 * max(Cr * TCN_HIDDEN, TCN_HIDDEN * ldC, Fr * ldC),), torch.float32)
         H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, s)
         X8 = d["X"][8]
         sTA, sTB = tA.shape[1] * R, tB.shape[1] * R
         H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, s)
         H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, s)
         self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
-        dXa = torch.empty(3, B, Tp, ldC, dtype=dt, device=dev)
-        dXb = torch.empty(3, B, Tp, ldC, dtype=dt, device=dev)
+        dXa = ws("dXa", (3, B, Tp, ldC))
+        dXb = ws("dXb", (3, B, Tp, ldC))
         H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
                X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
-        del dpre_fb
         # ---- 6. TCN blocks in reverse
         sAct = B * Tp * TCN_HIDDEN
-        h1b = torch.empty(3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
-        h2b = torch.empty(3, B, Tp, TCN_HIDDEN, dtype=dt, device=dev)
-        Sgn = torch.empty(3, B, 2, dtype=torch.float64, device=dev)
+        h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
+        h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
+        Sgn = ws("Sgn", (3, B, 2), torch.float64)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):
             pre = f"fb_model.sequence_model.{i}."
@@ -427,7 +424,7 @@ class FSNEngine:
             dXo, dXi = dXi, dXo
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
         sv = d["tsse_saved"]
-        dsg = torch.empty(B, F, dtype=torch.float32, device=dev)
+        dsg = ws("dsg", (B, F), torch.float32)
         maps = d["maps"]
         for z, br in enumerate(BRANCHES):
             att = f"channel_attention{br}."

@@ -34,8 +34,12 @@ class _DirectionNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.net.engine()
-        gflat = eng.backward(dout.contiguous().float())
+        eng.backward(dout.contiguous().float())
         grads = [None] * ctx.n_maps_tensors
+        if ctx.net.flat_grad_only:
+            # the caller (NPPCAudioTrainer.train_step) consumes the flat gradient buffer directly: one all-reduce, one
+            # Adam launch; handing 340 views to autograd would only make it copy each of them into .grad
+            return (None, None, *grads, *([None] * len(eng.fp.named)))
         for n, p in ctx.net.named_parameters():
             grads.append(eng.fp.gview(n) if p.requires_grad else None)
         return (None, None, *grads)
@@ -50,6 +54,7 @@ class MultiDirectionFullSubNet_Plus(FullSubNet_Plus):
         config.output_size = 2 * config.n_directions   # networks.py:23 (mutates the config, like the reference)
         super().__init__(config)
         self.n_directions = config.n_directions
+        self.flat_grad_only = False
         F = self.num_freqs
         # the full-band models are rebuilt for the concatenated (noisy ++ enhanced) input, networks.py:32-61
         self.fb_model = _SeqModel(2 * F, F, config.fb_model_hidden_size, "TCN")

@@ -57,6 +57,19 @@ def padded_rows(N):
     return (N + 31) // 32 * 32
 
 
+_WS = {}
+
+
+def workspace(key, shape, dtype, device, zero=False):
+    """Step-persistent device workspace (allocated, and if asked zeroed, ONCE: kernels never touch the padding)."""
+    k = (key, tuple(shape), dtype, str(device))
+    t = _WS.get(k)
+    if t is None:
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+        _WS[k] = t
+    return t
+
+
 def lstm2_forward(x_tm, packed, train, mtile=None):
     """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1T, h2T, g1, g2, c1, c2]).
     Transposed tensors are [rows][Tn*Np] with column t*Np + n (Np = padded_rows(N), padding zero)."""
@@ -65,15 +78,16 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
     assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
     dt, dev = x_tm.dtype, x_tm.device
-    out = {"h2": torch.empty(Tn, N, Hd, dtype=dt, device=dev)}
+    tag = ("lstm", id(packed), train)
+    out = {"h2": workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)}
     if train:
         Hr = (Hd + 127) // 128 * 128       # row padding so the tensors can be GEMM B-operands (N % 128 == 0)
-        out["h1T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
-        out["h2T"] = torch.zeros(Hr, Tn * Np, dtype=dt, device=dev)
-        out["c1"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
-        out["c2"] = torch.empty(Tn, N, Hd, dtype=dt, device=dev)
-        out["g1"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
-        out["g2"] = torch.empty(Tn, N, Hd, 4, dtype=dt, device=dev)
+        out["h1T"] = workspace(tag + ("h1T",), (Hr, Tn * Np), dt, dev, zero=True)
+        out["h2T"] = workspace(tag + ("h2T",), (Hr, Tn * Np), dt, dev, zero=True)
+        out["c1"] = workspace(tag + ("c1",), (Tn, N, Hd), dt, dev)
+        out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
+        out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
+        out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
     _timed(("lstm2_fwd", int(train), N, Tn, mtile), lambda: H.call(
@@ -106,10 +120,11 @@ def lstm2_backward(saved, dh2, packed_bwd, kx):
     Tn, N, Hd = saved["h2"].shape
     dt, dev = dh2.dtype, dh2.device
     Np = padded_rows(N)
-    dx = torch.empty(Tn, N, kx, dtype=dt, device=dev)
+    tag = ("lstm_bwd", id(packed_bwd))
+    dx = workspace(tag + ("dx",), (Tn, N, kx), dt, dev)
     Kr = (4 * Hd + 127) // 128 * 128   # row padding so the tensors can be GEMM A-operands (R % 128 == 0)
-    dg1T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
-    dg2T = torch.zeros(Kr, Tn * Np, dtype=dt, device=dev)
+    dg1T = workspace(tag + ("dg1T",), (Kr, Tn * Np), dt, dev, zero=True)
+    dg2T = workspace(tag + ("dg2T",), (Kr, Tn * Np), dt, dev, zero=True)
     _timed(("lstm2_bwd", 1, N, Tn, 1), lambda: H.call(
         "nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
         packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream()))

@@ -246,25 +246,26 @@ class NPPCAudioTrainer(nn.Module):
 
     # ---------------------------------------------------------------------------------- one optimisation step
     def train_step(self, batch):
-        """forward + loss + backward (+ gradient all-reduce over RCCL) + Adam; returns (reconst_err, objective, log)."""
-        reconst_err, objective, log = self.base_step(batch)
-        self.optimizer.zero_grad()
-        objective.backward()
+        """forward + loss + backward (+ gradient all-reduce over RCCL) + Adam; returns (reconst_err, objective, log).
+
+        With HipAdam (the reference's yaml optimizer) the direction net's gradient never leaves its flat buffer:
+        backward writes it, ONE all-reduce sums it across ranks, ONE Adam launch applies it (1/world folded into the
+        kernel's gradient scale).  Any other torch optimizer goes through .grad like the reference loop."""
         net = self.nppc_model.audio_pc_wrapper.net
+        fast = isinstance(self.optimizer, HipAdam)
+        net.flat_grad_only = fast
+        try:
+            reconst_err, objective, log = self.base_step(batch)
+            self.optimizer.zero_grad()
+            objective.backward()
+        finally:
+            net.flat_grad_only = False
         eng = net.engine()
-        gflat = eng.fp.grad
-        first = eng.fp.named[0][1]
-        flat_ok = (isinstance(self.optimizer, HipAdam) and gflat is not None and first.grad is not None
-                   and first.grad.data_ptr() == gflat.data_ptr())
-        if self.world > 1:
-            if flat_ok:
-                torch.distributed.all_reduce(gflat)          # sum; the mean's 1/W is folded into Adam's grad scale
-            else:
-                for p in net.parameters():
-                    if p.grad is not None:
-                        torch.distributed.all_reduce(p.grad)
         scale = 1.0 / self.world
-        if flat_ok:
+        if fast:
+            gflat = eng.fp.grad
+            if self.world > 1:
+                torch.distributed.all_reduce(gflat)          # sum; the mean's 1/W is folded into Adam's grad scale
             if self._flat_adam is None or self._flat_adam.eng is not eng:
                 self._flat_adam = FlatAdamStepper(self.optimizer, eng)
             self._flat_adam.step(gflat, scale)
@@ -272,6 +273,7 @@ class NPPCAudioTrainer(nn.Module):
             if self.world > 1:
                 for p in net.parameters():
                     if p.grad is not None:
+                        torch.distributed.all_reduce(p.grad)
                         p.grad.mul_(scale)
             self.optimizer.step()
         self.step += 1
