@@ -79,6 +79,79 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
   }
 }
 
+// ---------------------------------------------------------------- iSTFT
+// torch.istft(center=True, periodic hann, onesided input, length=L): y[p] = sum_t w[p - t*hop] x_t[p - t*hop] / sum_t w^2[p - t*hop],
+// x_t = irfft(X_t), p = n + N/2.  One workgroup = ISTFT_FR*hop consecutive output samples of one clip; it inverts the
+// ISTFT_FR + N/hop - 1 frames that overlap them (radix-2 in LDS on the Hermitian-extended spectrum).
+constexpr int ISTFT_FR = 4;
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void istft_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                    float* __restrict__ out, int T, int hop, int L) {
+  constexpr int N = 1 << LOGN;
+  constexpr int F = N / 2 + 1;
+  constexpr int MAXFR = ISTFT_FR + 7;            // supports hop >= N/8
+  __shared__ float2 buf[MAXFR][N + 1];
+  __shared__ float2 tw[N / 2];
+  __shared__ float win[N];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int ov = N / hop;                          // frames overlapping one sample
+  const int nfr = ISTFT_FR + ov - 1;
+  const int p0 = blockIdx.x * ISTFT_FR * hop;      // first padded-coordinate sample of this block
+  const int tfirst = p0 / hop - (ov - 1);          // first frame that can touch [p0, p0 + FR*hop)
+  for (int i = tid; i < N / 2; i += 256) {
+    double s, c;
+    sincospi(2.0 * i / N, &s, &c);                 // inverse transform: +i
+    tw[i] = make_float2((float)c, (float)s);
+  }
+  for (int i = tid; i < N; i += 256) win[i] = (float)(0.5 - 0.5 * cospi(2.0 * i / N));
+  __syncthreads();
+  for (int e = tid; e < nfr * N; e += 256) {
+    const int j = e / N, k = e % N;
+    const int t = tfirst + j;
+    float2 v = make_float2(0.f, 0.f);
+    if (t >= 0 && t < T) {
+      const int kk = k < F ? k : N - k;
+      const size_t o = ((size_t)b * F + kk) * T + t;
+      v = make_float2(re[o], k < F ? im[o] : -im[o]);
+      if (k == 0 || k == N / 2) v.y = 0.f;         // irfft ignores the imaginary part of DC / Nyquist
+    }
+    buf[j][__brev((unsigned)k) >> (32 - LOGN)] = v;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < LOGN; ++s) {
+    const int half = 1 << s;
+    for (int e = tid; e < nfr * (N / 2); e += 256) {
+      const int j = e / (N / 2), k = e % (N / 2);
+      const int grp = k >> s, pos = k & (half - 1);
+      const int i0 = (grp << (s + 1)) + pos, i1 = i0 + half;
+      const float2 w = tw[pos << (LOGN - 1 - s)];
+      const float2 a = buf[j][i0], c = buf[j][i1];
+      const float xr = c.x * w.x - c.y * w.y, xi = c.x * w.y + c.y * w.x;
+      buf[j][i0] = make_float2(a.x + xr, a.y + xi);
+      buf[j][i1] = make_float2(a.x - xr, a.y - xi);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < ISTFT_FR * hop; e += 256) {
+    const int p = p0 + e;
+    const int nidx = p - N / 2;
+    if (nidx < 0 || nidx >= L) continue;
+    float num = 0.f, den = 0.f;
+    for (int j = 0; j < nfr; ++j) {
+      const int t = tfirst + j;
+      const int off = p - t * hop;
+      if (t >= 0 && t < T && off >= 0 && off < N) {
+        const float w = win[off];
+        num += w * buf[j][off].x * (1.0f / N);
+        den += w * w;
+      }
+    }
+    out[(size_t)b * L + nidx] = den > 1e-11f ? num / den : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------- drop-band index math
 // drop_band(x[B,C,F,T], G): F trimmed to F - F%G, output batch = groups concatenated
 // (group g = samples g, g+G, ...), sample of group g keeps bins g, g+G, ...
@@ -147,15 +220,21 @@ __device__ __forceinline__ float decompress_cirm(float m) {
 // crm [B][2][F][T] compressed -> dec [B][F][T][2] (optional), enhanced mag/re/im [B][F][T]
 __global__ void decompress_apply_kernel(const float* __restrict__ crm, const float* __restrict__ nr,
                                         const float* __restrict__ ni, float* __restrict__ dec, float* __restrict__ emag,
-                                        float* __restrict__ ere, float* __restrict__ eim, int B, int F, int T) {
+                                        float* __restrict__ ere, float* __restrict__ eim, int B, int F, int T, int conj_mask) {
   const size_t FT = (size_t)F * T, total = (size_t)B * FT;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const size_t b = e / FT, r = e % FT;
     const float mr = decompress_cirm(crm[(b * 2) * FT + r]);
     const float mi = decompress_cirm(crm[(b * 2 + 1) * FT + r]);
     const float a = nr[e], c = ni[e];
-    const float xr = mr * a + mi * c;   // conj(mask) * noisy: the reference's swapped call (utils.py:241-249)
-    const float xi = mr * c - mi * a;
+    float xr, xi;
+    if (conj_mask) {       // conj(mask) * noisy: the reference's swapped call in the TRAIN path (utils.py:241-249)
+      xr = mr * a + mi * c;
+      xi = mr * c - mi * a;
+    } else {               // mask * noisy: model_outputs_to_waveforms / validator (utils.py:37-72, :252-256)
+      xr = mr * a - mi * c;
+      xi = mi * a + mr * c;
+    }
     if (dec) { dec[2 * e] = mr; dec[2 * e + 1] = mi; }
     ere[e] = xr;
     eim[e] = xi;
@@ -211,7 +290,32 @@ int nppc_cirm_decompress_apply_conj(const float* crm, const float* nr, const flo
                                     float* ere, float* eim, int B, int F, int T, void* stream) {
   if (!crm || !nr || !ni || !emag || !ere || !eim || B <= 0) return NPPC_EBADARG;
   hipLaunchKernelGGL(decompress_apply_kernel, dim3(ew_grid((size_t)B * F * T)), dim3(256), 0, (hipStream_t)stream, crm, nr,
-                     ni, dec, emag, ere, eim, B, F, T);
+                     ni, dec, emag, ere, eim, B, F, T, 1);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_cirm_decompress_apply(const float* crm, const float* nr, const float* ni, float* dec, float* emag, float* ere,
+                               float* eim, int B, int F, int T, void* stream) {
+  if (!crm || !nr || !ni || !emag || !ere || !eim || B <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(decompress_apply_kernel, dim3(ew_grid((size_t)B * F * T)), dim3(256), 0, (hipStream_t)stream, crm, nr,
+                     ni, dec, emag, ere, eim, B, F, T, 0);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_istft(const float* re, const float* im, float* out, int B, int T, int nfft, int hop, int L, void* stream) {
+  if (!re || !im || !out || B <= 0 || T <= 0 || hop <= 0 || L <= 0 || nfft % hop || nfft / hop > 8) return NPPC_EBADARG;
+  const int total = L + nfft / 2;                     // padded samples that can reach the output
+  dim3 grid(ceil_div(total, ISTFT_FR * hop), B);
+  hipStream_t s = (hipStream_t)stream;
+  switch (nfft) {
+    case 64: hipLaunchKernelGGL(istft_kernel<6>, grid, dim3(256), 0, s, re, im, out, T, hop, L); break;
+    case 128: hipLaunchKernelGGL(istft_kernel<7>, grid, dim3(256), 0, s, re, im, out, T, hop, L); break;
+    case 256: hipLaunchKernelGGL(istft_kernel<8>, grid, dim3(256), 0, s, re, im, out, T, hop, L); break;
+    case 512: hipLaunchKernelGGL(istft_kernel<9>, grid, dim3(256), 0, s, re, im, out, T, hop, L); break;
+    default: return NPPC_EUNSUPPORTED;
+  }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

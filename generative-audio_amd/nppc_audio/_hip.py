@@ -76,6 +76,8 @@ SIGS = {
     "nppc_dropband": [P, P, I, I, I, I, I, P],
     "nppc_cirm_build_compress": [P, P, P, P, P, I, I, I, I, F, P],
     "nppc_cirm_decompress_apply_conj": [P, P, P, P, P, P, P, I, I, I, P],
+    "nppc_cirm_decompress_apply": [P, P, P, P, P, P, P, I, I, I, P],
+    "nppc_istft": [P, P, P, I, I, I, I, I, P],
     "nppc_rowsum": [P, P, L, I, P],
     "nppc_tsse_fwd": [P, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],

@@ -66,3 +66,31 @@ def cirm_decompress_apply_conj(crm, n_re, n_im, want_dec=False):
     dec = torch.empty(B, F, T, 2, dtype=torch.float32, device=crm.device) if want_dec else None
     H.call("nppc_cirm_decompress_apply_conj", crm, n_re, n_im, dec, emag, ere, eim, B, F, T, H.stream())
     return dec, emag, ere, eim
+
+
+def cirm_decompress_apply(crm, n_re, n_im):
+    """decompress_cIRM + TRUE complex product mask*noisy (utils.py:37-58: model_outputs_to_waveforms' mask application).
+    crm [B,2,F,T] compressed -> (enh_mag, enh_real, enh_imag) [B,F,T]."""
+    crm, n_re, n_im = _f32c(crm), _f32c(n_re), _f32c(n_im)
+    B, _, F, T = crm.shape
+    emag = torch.empty(B, F, T, dtype=torch.float32, device=crm.device)
+    ere, eim = torch.empty_like(emag), torch.empty_like(emag)
+    H.call("nppc_cirm_decompress_apply", crm, n_re, n_im, None, emag, ere, eim, B, F, T, H.stream())
+    return emag, ere, eim
+
+
+def istft(re, im, nfft, hop, length):
+    """torch.istft(n_fft, hop, win_length=n_fft, hann window, center=True, length=length): [B,F,T] x2 -> [B,length]
+    (utils.py:60-70, nppc_audio/validator.py:136-143)."""
+    re, im = _f32c(re), _f32c(im)
+    B, F, T = re.shape
+    assert F == nfft // 2 + 1
+    out = torch.empty(B, length, dtype=torch.float32, device=re.device)
+    H.call("nppc_istft", re, im, out, B, T, nfft, hop, length, H.stream())
+    return out
+
+
+def model_outputs_to_waveforms(enhanced_masks, noisy_reals, noisy_imags, orig_length, nfft=512, hop=256):
+    """utils.py:37-72: compressed cIRM [B,2,F,T] + noisy STFT [B,1,F,T] -> enhanced waveforms [B, orig_length]."""
+    _, ere, eim = cirm_decompress_apply(enhanced_masks, noisy_reals.squeeze(1), noisy_imags.squeeze(1))
+    return istft(ere, eim, nfft, hop, orig_length)

@@ -31,6 +31,12 @@ int nppc_cirm_build_compress(const float* nr, const float* ni, const float* cr, 
 int nppc_cirm_decompress_apply_conj(const float* crm, const float* nr, const float* ni, float* dec /*nullable*/,
                                     float* emag, float* ere, float* eim, int B, int F, int T, void* stream);
 
+/* the same with the true product mask*noisy: utils.model_outputs_to_waveforms (utils.py:37-58), crm_to_spectogram (:252-256) */
+int nppc_cirm_decompress_apply(const float* crm, const float* nr, const float* ni, float* dec /*nullable*/, float* emag,
+                               float* ere, float* eim, int B, int F, int T, void* stream);
+/* torch.istft(center, periodic hann, length=L): utils.py:60-70, nppc_audio/validator.py:136-143 */
+int nppc_istft(const float* re, const float* im, float* out, int B, int T, int nfft, int hop, int L, void* stream);
+
 /* ---- full-band front: offline_laplace_norm + ChannelTimeSenseSELayer ---------------------------------------
  * audio_zen/model/base_model.py:210-224, audio_zen/model/module/attention_model.py:43-98,
  * fullsubnet_plus.py:158-185, nppc_audio/networks.py:80-112 */

@@ -58,6 +58,21 @@ def apply_mask_swapped(mask_re, mask_im, n_re, n_im):
     return torch.sqrt(e_re * e_re + e_im * e_im), e_re, e_im
 
 
+def istft_wave(re, im, nfft, hop, length):
+    """utils.py:60-70 / validator.py:136-143: torch.istft with the periodic hann window, centred, length-cropped."""
+    w = torch.hann_window(nfft, dtype=re.dtype)
+    return torch.istft(torch.complex(re, im), n_fft=nfft, hop_length=hop, win_length=nfft, window=w, center=True,
+                       return_complex=False, length=length)
+
+
+def outputs_to_waveforms(mask, n_re, n_im, length, nfft=512, hop=256):
+    """utils.py:37-72 (model_outputs_to_waveforms): decompress, TRUE product mask*noisy, iSTFT.  mask [B,2,F,T]."""
+    d = decompress_mask(mask)
+    e_re = d[:, 0] * n_re - d[:, 1] * n_im
+    e_im = d[:, 1] * n_re + d[:, 0] * n_im
+    return istft_wave(e_re, e_im, nfft, hop, length)
+
+
 def band_drop(x, groups):
     """feature.py:254-285 on [B,C,F,T]."""
     B, _, F, _ = x.shape

@@ -112,3 +112,24 @@ def test_restorer_forward_matches_reference(name, precision, tol):
     assert report["out"] < tol, report
     # fp32 tolerance note: reference fp32-vs-fp64 floor for pred_crm is 1.2e-5; the laplace
     # norm of the signed real/imag maps amplifies summation-order differences (hard part b)
+
+
+@pytest.mark.parametrize("name", ["g0_tiny", "g1_c1"])
+def test_istft_roundtrip_and_enhanced_waveform(name):
+    """iSTFT (north-star front end; used by utils.model_outputs_to_waveforms / the validator) vs torch.istft."""
+    from nppc_audio import ops
+    z, meta = load(name)
+    c = meta["config"]
+    L = c["L"]
+    wave = torch.from_numpy(z["noisy"])
+    _, re, im = ops.stft(wave.cuda(), c["nfft"], c["hop"])
+    back = ops.istft(re, im, c["nfft"], c["hop"], L).cpu()
+    assert (back - wave).abs().max().item() < 2e-6                   # STFT -> iSTFT is the identity (NOLA holds)
+    n_re, n_im = torch.from_numpy(z["noisy_real"][:, 0]), torch.from_numpy(z["noisy_imag"][:, 0])
+    ref = R.istft_wave(n_re, n_im, c["nfft"], c["hop"], L - 37)     # odd crop length
+    got = ops.istft(n_re.cuda(), n_im.cuda(), c["nfft"], c["hop"], L - 37).cpu()
+    assert (got - ref).abs().max().item() < 2e-6
+    mask = torch.from_numpy(z["pred_crm_full"])
+    ref = R.outputs_to_waveforms(mask, n_re, n_im, L, c["nfft"], c["hop"])
+    got = ops.model_outputs_to_waveforms(mask.cuda(), n_re[:, None].cuda(), n_im[:, None].cuda(), L, c["nfft"], c["hop"]).cpu()
+    assert (got - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
