@@ -69,6 +69,8 @@ SIGS = {
     "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
     "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
     "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
+    "nppc_lstm2_coop_plan": [I, I, L, I, I, PI, PI, PI],
+    "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
     "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
     "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],

@@ -58,6 +58,20 @@ def padded_rows(N):
 
 
 _WS = {}
+COOP = True          # use the cooperative (weights split over CU pairs) forward kernel when the shape allows it
+N_CU = None
+
+
+def _n_cu():
+    global N_CU
+    if N_CU is None:
+        N_CU = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return N_CU
+
+
+def coop_timeouts():
+    """Number of cooperative launches whose bounded spins gave up (0 on a healthy run); reads the device."""
+    return sum(int(t[-4].item()) for k, t in _WS.items() if k[0][-1] == "coop_flags")
 
 
 def workspace(key, shape, dtype, device, zero=False):
@@ -88,6 +102,19 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
+    if COOP and mtile is None:
+        G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        H.call("nppc_lstm2_coop_plan", packed.prec, int(train), N, Hd, _n_cu(), ctypes.byref(G), ctypes.byref(cmt),
+               ctypes.byref(ncl))
+        if ncl.value > 0:
+            G, cmt, ncl = G.value, cmt.value, ncl.value
+            xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 16 * cmt * Hd,), dt, dev)
+            flags = workspace(tag + ("coop_flags",), (ncl * 2 * G + 4,), torch.int32, dev, zero=True)
+            _timed(("lstm2_fwd_coop", int(train), N, Tn, cmt), lambda: H.call(
+                "nppc_lstm2_fwd_coop", packed.prec, int(train), G, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
+                packed.bias2, out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"),
+                out.get("c2"), xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, Np, H.stream()))
+            return out
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
     _timed(("lstm2_fwd", int(train), N, Tn, mtile), lambda: H.call(

@@ -113,6 +113,14 @@ int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, co
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
                    const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
                    int Tn, int I, int H, long Np, void* stream);
+/* Cooperative forward: G workgroups (CUs) share a tile of 16*mtile sequences and split the hidden units, each streaming
+ * 1/G of the weights; h slices cross CUs through `xch` with bounded-spin epoch flags (`flags`, zeroed by the launcher;
+ * the word after the last flag is set on a spin timeout).  Same tensor contract as nppc_lstm2_fwd. */
+int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, int* mtile, int* clusters);
+int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
+                        const float* bias1, const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1,
+                        void* c2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, long Np,
+                        void* stream);
 int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
 int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
                                 int I, int H, void* wb1, void* wb2, void* stream);
