@@ -102,7 +102,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   constexpr int OX0 = 0, OX1 = KX, OH1 = 2 * KX, OH2 = 2 * KX + H;
   constexpr int NKX = KX / 32, NKH = H / 32;
   constexpr int nk1 = NKX + NKH, nk2 = 2 * NKH;
-  constexpr int DEPTH = MT <= 2 ? 4 : 2;                          // weight-fragment ring depth the register budget allows
+  constexpr int DEPTH = (MT <= 2 || G == 4) ? 4 : 2;              // weight-fragment ring depth the register budget allows
   constexpr int SLICE = MC * HC;                                  // elements of one CU's h slice
   constexpr int SLICE_CH = SLICE * (int)sizeof(T) / 16;           // 16-byte chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -370,13 +370,13 @@ extern "C" {
 int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, int* mtile, int* clusters) {
   *G = 0; *mtile = 0; *clusters = 0;
   if (prec != NPPC_PREC_BF16 || H != 384 || N <= 0) return NPPC_OK;
-  const int g = 2;
-  const int options[2] = {2, 5};
-  for (int oi = 0; oi < 2; ++oi) {
-    const int mt = options[oi];
-    if (train && mt != 2) continue;
+  // candidates (G, mtile), most CUs first: the stream per CU shrinks with G, the rows per cluster grow with mtile
+  const int cand[3][2] = {{2, 2}, {4, 4}, {2, 5}};   // measured at N = 4096: G = 2 beats G = 4 (6 waves leave two SIMDs idle)
+  for (int oi = 0; oi < 3; ++oi) {
+    const int g = cand[oi][0], mt = cand[oi][1];
+    if (train && mt == 5) continue;
     const long cl = (N + 16 * mt - 1) / (16 * mt);
-    if (cl * g <= n_cu) { *G = g; *mtile = mt; *clusters = (int)cl; return NPPC_OK; }
+    if (cl * g <= n_cu && (cl * g * 2 > n_cu || oi == 2)) { *G = g; *mtile = mt; *clusters = (int)cl; return NPPC_OK; }
   }
   return NPPC_OK;
 }
@@ -386,12 +386,16 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
                         const float* bias1, const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1,
                         void* c2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, long Np,
                         void* stream) {
-  if (prec != NPPC_PREC_BF16 || H != 384 || G != 2) return NPPC_EUNSUPPORTED;
+  if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4)) return NPPC_EUNSUPPORTED;
   if (!x || !wp1 || !wp2 || !h2 || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
   if (train && (!h1T || !h2T || !g1 || !g2 || !c1 || !c2 || Np < N)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
   CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, xch, flags, N, Tn, Np, (int)((N + MC - 1) / MC)};
   hipStream_t s = (hipStream_t)stream;
+  if (G == 4) {
+    if (mtile != 4) return NPPC_EUNSUPPORTED;
+    return train ? launch_coop<bf16_t, 4, 4, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 4, 4, false>(a, (size_t)xch_bytes, s);
+  }
   if (train) {
     if (mtile == 2) return launch_coop<bf16_t, 2, 2, true>(a, (size_t)xch_bytes, s);
     return NPPC_EUNSUPPORTED;

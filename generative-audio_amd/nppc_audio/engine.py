@@ -269,9 +269,7 @@ class FSNEngine:
         H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
                self.nb, self.G, self.KX, s)
         # 7: two-layer LSTM over T' steps for the B*F' sequences
-        if mtile is None:
-            mtile = pick_mtile(d["Nseq"], prec, train)
-        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile)
+        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile)      # mtile None: cooperative kernel when the shape allows
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
         out = torch.empty(B, self.O, d["Fo"], T, dtype=torch.float32, device=self.dev)

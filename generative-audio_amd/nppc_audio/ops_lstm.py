@@ -102,15 +102,20 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
-    if COOP and mtile is None:
+    if (COOP and mtile is None) or isinstance(mtile, tuple):
         G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        H.call("nppc_lstm2_coop_plan", packed.prec, int(train), N, Hd, _n_cu(), ctypes.byref(G), ctypes.byref(cmt),
-               ctypes.byref(ncl))
+        if isinstance(mtile, tuple):               # (G, mtile) forced by a test / benchmark
+            G.value, cmt.value = mtile
+            ncl.value = (N + 16 * cmt.value - 1) // (16 * cmt.value)
+            assert ncl.value * G.value <= _n_cu(), "cooperative launch needs one CU per workgroup"
+        else:
+            H.call("nppc_lstm2_coop_plan", packed.prec, int(train), N, Hd, _n_cu(), ctypes.byref(G), ctypes.byref(cmt),
+                   ctypes.byref(ncl))
         if ncl.value > 0:
             G, cmt, ncl = G.value, cmt.value, ncl.value
             xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 16 * cmt * Hd,), dt, dev)
             flags = workspace(tag + ("coop_flags",), (ncl * 2 * G + 4,), torch.int32, dev, zero=True)
-            _timed(("lstm2_fwd_coop", int(train), N, Tn, cmt), lambda: H.call(
+            _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
                 "nppc_lstm2_fwd_coop", packed.prec, int(train), G, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
                 packed.bias2, out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"),
                 out.get("c2"), xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, Np, H.stream()))

@@ -152,8 +152,9 @@ def test_lstm_bwd_matches_autograd(Hd, I, prec, tol):
         assert r < tol, (n, r)
 
 
-@pytest.mark.parametrize("N,Tn,train", [(50, 23, False), (50, 23, True), (200, 9, False), (4096 // 8, 7, True)])
-def test_cooperative_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train):
+@pytest.mark.parametrize("N,Tn,train,force", [(50, 23, False, (2, 2)), (50, 23, True, (2, 2)), (200, 9, False, (2, 5)),
+                                              (512, 7, True, (4, 4)), (100, 11, False, (4, 4)), (777, 5, True, (2, 2))])
+def test_cooperative_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train, force):
     """The CU-pair kernel (weights split over two workgroups, h slices exchanged through global memory) must give
     the same numbers as the single-workgroup kernel, and no bounded spin may time out."""
     from nppc_audio import _hip as H
@@ -169,16 +170,9 @@ def test_cooperative_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, t
     x = torch.randn(N, Tn, I, generator=g)
     xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
     xt[:, :, :I] = x.permute(1, 0, 2).to(dev)
-    ops_lstm.COOP = True
-    try:
-        coop = {k: v.clone() for k, v in lstm2_forward(xt, pk, train).items()}
-        assert ops_lstm.coop_timeouts() == 0
-    finally:
-        ops_lstm.COOP = False
-    try:
-        single = {k: v.clone() for k, v in lstm2_forward(xt, pk, train, 1).items()}
-    finally:
-        ops_lstm.COOP = True
+    coop = {k: v.clone() for k, v in lstm2_forward(xt, pk, train, force).items()}
+    assert ops_lstm.coop_timeouts() == 0
+    single = {k: v.clone() for k, v in lstm2_forward(xt, pk, train, 1).items()}
     torch.cuda.synchronize()
     ref = R.lstm2(x, P, "sb_model.sequence_model")
     got = coop["h2"].float().cpu().permute(1, 0, 2)

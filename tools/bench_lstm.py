@@ -15,7 +15,7 @@ ws = [w.to(dev) for w in ws]
 precs = ((0, "bf16"),) if "--bf16" in sys.argv else ((0, "bf16"), (1, "f32"))
 for prec, name in precs:
     pk = PackedLSTM(I, Hd, prec, dev).pack(*ws)
-    for N, train, mts in ((8224, False, (None, 3)), (4096, True, (None, 1)), (4096, False, (None, 1))):
+    for N, train, mts in ((8224, False, ((2, 5), 3)), (4096, True, ((4, 4), (2, 2), 1)), (4096, False, ((4, 4), (2, 2), 1))):
         if prec == 1:
             mts = (1,)
             if N == 8224:
@@ -33,5 +33,5 @@ for prec, name in precs:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
             flops = N * Tn * 2 * 1536 * (34 + 384 + 768)
-            print(f"{name} N={N} train={train} mtile={'coop' if mt is None else mt}: {dt*1e3:.2f} ms  {flops/dt/1e12:.1f} TFLOP/s "
+            print(f"{name} N={N} train={train} mtile={mt}: {dt*1e3:.2f} ms  {flops/dt/1e12:.1f} TFLOP/s "
                   f"finite={bool(torch.isfinite(out['h2'].float()).all())} timeouts={ops_lstm.coop_timeouts()}", flush=True)
