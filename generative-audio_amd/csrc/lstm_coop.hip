@@ -48,10 +48,23 @@ __device__ __forceinline__ int frag_boff(int gp, int ublk, int kk, int s, int nk
   return ((((gp * 8 + w8) * nk + kk) * 3 + ub3) * 2 + s) * 512 * (int)sizeof(T);
 }
 
-template <typename T, int MT, int RS, int DEPTH>
+// The first DEPTH-1 weight stages of a segment can be fetched EARLY (before the barrier / cell update / hand-off that
+// precedes the GEMM) with coop_prime and handed to coop_gemm: the weight stream then never restarts cold.
+template <typename T, int DEPTH>
+__device__ __forceinline__ void coop_prime(typename Frag<T>::type (&pre)[DEPTH - 1][2], int n, int koff, int nk,
+                                           __amdgpu_buffer_rsrc_t wr, int gp, int ublk, int lane) {
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if (d < n) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) pre[d][s] = BFrag<T>::load(wr, lane, frag_boff<T>(gp, ublk, koff + d, s, nk));
+    }
+}
+
+template <typename T, int MT, int RS, int DEPTH, bool PRIMED = false>
 __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /* row n, col 8q of the segment */, int k0, int k1,
                                           int koff /* packed k-step of segment start */, int nk, __amdgpu_buffer_rsrc_t wr, int gp,
-                                          int ublk, int lane) {
+                                          int ublk, int lane, typename Frag<T>::type (*pre)[2] = nullptr) {
   typedef typename Frag<T>::type frag;
   auto loadb = [&](frag(&b)[2], int kk) {
 #pragma unroll
@@ -69,8 +82,10 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /
   frag b[DEPTH][2];
   const int n = k1 - k0;
 #pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d)
-    if (d < n) loadb(b[d], k0 + d);
+  for (int d = 0; d < DEPTH - 1; ++d) {
+    if (PRIMED) { b[d][0] = pre[d][0]; b[d][1] = pre[d][1]; }
+    else if (d < n) loadb(b[d], k0 + d);
+  }
 #pragma unroll 1
   for (int kk = 0; kk < n; kk += DEPTH) {
 #pragma unroll
@@ -222,6 +237,8 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         }
       }
     }
+    constexpr bool PR = MT <= 2;                                   // prime the next weight segment across sync points
+    typename Frag<T>::type pre[DEPTH - 1][2];
     // ================= layer 1: [x_t | h1_{t-1}] =================
     float iv1[TRAIN ? MT : 1][4], gv1[TRAIN ? MT : 1][4];
     f32x4 ig[MT];
@@ -265,6 +282,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           }
         }
     }
+    if (PR) coop_prime<T, DEPTH>(pre, NKH, NKH, nk2, wr2, 0, ublk, lane);       // layer 2, pair (i,g), h2 half
     // the partners' h2_{t-1} (published at the end of the previous step) -> LDS; nobody reads H2 during layer 1
     if (t > 0) consume(1, OH2, ep - 1);
     __syncthreads();                                              // (1) all waves done reading h1_{t-1} and x_t
@@ -292,10 +310,11 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       f32x4 acc[2][MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH2, 0, NKH, NKH, nk2, wr2, 0, ublk, lane);
+      coop_gemm<T, MT, RS, DEPTH, PR>(acc, a_lane + OH2, 0, NKH, NKH, nk2, wr2, 0, ublk, lane, pre);
+      if (PR) coop_prime<T, DEPTH>(pre, NKH, 0, nk2, wr2, 0, ublk, lane);       // h1 half: in flight during the hand-off
       consume(0, OH1, ep);
       __syncthreads();                                            // (2c) full h1_t in LDS
-      coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, 0, nk2, wr2, 0, ublk, lane);
+      coop_gemm<T, MT, RS, DEPTH, PR>(acc, a_lane + OH1, 0, NKH, 0, nk2, wr2, 0, ublk, lane, pre);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -340,6 +359,293 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int j = 0; j < 4; ++j) hw_lane[OH2 + (16 * mt + j) * RS] = from_f32<T>(hn2[mt][j]);
     __syncthreads();                                              // own h2_t slice complete in LDS
     if (more) publish(1, OH2, ep);
+  }
+}
+
+// =====================================================================================================
+// Cooperative backward recurrence: a CU pair shares a tile of 32 sequences; CU `cu` owns hidden units
+// [192*cu, 192*cu + 192) of both layers: it runs the cell backward for them, owns the matching output columns of the
+// two backward GEMMs (d h1 / d h2_prev / d h1_prev / half of d x) and streams only those columns' weights (half).
+// What crosses CUs per layer and step is the other half of the dgates tile [32][768] (48 KB), the MFMA A operand.
+struct CoopBwdArgs {
+  const void* g1; const void* g2; const void* c1; const void* c2; const void* dh2;
+  const void* wb1; const void* wb2;   // packed by lstm_coop_pack_bwd_kernel
+  void* dx; void* dg1T; void* dg2T;
+  void* xch;                          // [clusters][2 layers][2 parities][2 CUs][32][768]
+  unsigned* flags;                    // [clusters][2 layers][2] epochs + timeout word
+  long N; int Tn; long Np; int clusters;
+};
+
+constexpr int CB_G = 2, CB_MC = 32, CB_H = 384, CB_HC = 192, CB_KX = 64, CB_NW = 12, CB_NT = CB_NW * 64;
+constexpr int CB_K4 = 4 * CB_H, CB_KC = 4 * CB_HC;        // gate columns: all / own
+constexpr int CB_NK = CB_K4 / 32;                          // 48 k-steps
+
+// B fragment (cu, wave, kk, slot): packed contiguously [cu][wave][kk][slot][lane][8]
+__device__ __forceinline__ int cb_frag_boff(int cu, int wave, int kk, int slot) {
+  return ((((cu * CB_NW + wave) * CB_NK + kk) * 2 + slot) * 512) * 2;
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void cb_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, int k0, int k1, __amdgpu_buffer_rsrc_t wr, int cu,
+                                        int wave, int lane, int RS) {
+  constexpr int DEPTH = 4;
+  bf16x8 b[DEPTH][2];
+  auto loadb = [&](bf16x8(&bb)[2], int kk) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) bb[s] = BFrag<bf16_t>::load(wr, lane, cb_frag_boff(cu, wave, kk, s));
+  };
+  auto compute = [&](const bf16x8(&bb)[2], int kk) {
+    bf16x8 af[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RS + 32 * kk);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[s][mt] = mma16(af[mt], bb[s], acc[s][mt]);
+  };
+  const int n = k1 - k0;
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if (d < n) loadb(b[d], k0 + d);
+#pragma unroll 1
+  for (int kk = 0; kk < n; kk += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int kl = kk + d + DEPTH - 1;
+      if (kl < n) loadb(b[(d + DEPTH - 1) % DEPTH], k0 + kl);
+      if (kk + d < n) compute(b[d], k0 + kk + d);
+    }
+  }
+}
+
+__global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
+  typedef bf16_t T;
+  constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
+  constexpr int RSA = CB_K4 + 8;                            // A tile row stride (elements)
+  constexpr int TPR = NT / MC, UPT = HC / TPR;              // 24 threads per row, 8 units per thread
+  constexpr int HALF_CH = MC * CB_KC * 2 / 16;              // 16-byte chunks of one dgates half (3072)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Abuf = reinterpret_cast<T*>(smem_raw);                                         // [32][RSA]
+  float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)MC * RSA * sizeof(T)); // [32][HC]  own units
+  float* dhrec2 = dh1buf + MC * HC;                                                  // [32][HC]
+
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cluster = blockIdx.x / CB_G, cu = blockIdx.x % CB_G, pcu = 1 - cu;
+  const long row0 = (long)cluster * MC;
+  const long N = a.N;
+  const long R = (long)a.Tn * a.Np;
+  for (int i = tid; i < 2 * MC * HC; i += NT) dh1buf[i] = 0.f;
+  for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
+
+  const int prow = tid / TPR, ul0 = (tid % TPR) * UPT, u0 = cu * HC + ul0;   // local / global first unit
+  const bool prow_ok = row0 + prow < N;
+  float dc1[UPT], dc2[UPT];
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) dc1[i] = dc2[i] = 0.f;
+
+  const T* g1 = reinterpret_cast<const T*>(a.g1);
+  const T* g2 = reinterpret_cast<const T*>(a.g2);
+  const T* c1 = reinterpret_cast<const T*>(a.c1);
+  const T* c2 = reinterpret_cast<const T*>(a.c2);
+  const T* dh2 = reinterpret_cast<const T*>(a.dh2);
+  T* dx = reinterpret_cast<T*>(a.dx);
+  T* dg1T = reinterpret_cast<T*>(a.dg1T);
+  T* dg2T = reinterpret_cast<T*>(a.dg2T);
+  constexpr unsigned WB = CB_G * CB_NW * CB_NK * 2 * 512 * 2;
+  const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wb1, WB), wr2 = make_rsrc(a.wb2, WB);
+  constexpr int XSL = MC * CB_KC;                                                   // elements of one dgates half
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const T*>(a.xch) + (size_t)cluster * 2 * 2 * 2 * XSL,
+                                              (unsigned)(2 * 2 * 2 * XSL * sizeof(T)));
+  gu32* flags = (gu32*)(a.flags + (size_t)cluster * 2 * CB_G);
+  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * 2 * CB_G);
+  const T* a_lane = Abuf + n * RSA + 8 * q;
+  __syncthreads();
+
+  struct Saved { T g[UPT * 4]; T ct[UPT]; T cp[UPT]; T dh[UPT]; };
+  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t) {
+    if (!prow_ok || t < 0) return;
+    const size_t e = ((size_t)t * N + row0 + prow) * H + u0;
+#pragma unroll
+    for (int i = 0; i < UPT * 4 * 2 / 16; ++i) reinterpret_cast<uint4*>(sv.g)[i] = reinterpret_cast<const uint4*>(gs + e * 4)[i];
+    *reinterpret_cast<uint4*>(sv.ct) = *reinterpret_cast<const uint4*>(cs + e);
+    if (t > 0) *reinterpret_cast<uint4*>(sv.cp) = *reinterpret_cast<const uint4*>(cs + e - (size_t)N * H);
+    if (dh_ext) *reinterpret_cast<uint4*>(sv.dh) = *reinterpret_cast<const uint4*>(dh_ext + e);
+  };
+  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float (&dc)[UPT], int t) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      float di = 0.f, dg = 0.f, df = 0.f, dO = 0.f;
+      if (prow_ok) {
+        const float iv = bf2f(sv.g[i * 4 + 0]), gv = bf2f(sv.g[i * 4 + 1]);
+        const float fv = bf2f(sv.g[i * 4 + 2]), ov = bf2f(sv.g[i * 4 + 3]);
+        const float ct = bf2f(sv.ct[i]);
+        const float cp = t > 0 ? bf2f(sv.cp[i]) : 0.f;
+        float dh = dh_lds[prow * HC + ul0 + i];
+        if (has_ext) dh += bf2f(sv.dh[i]);
+        const float tc = tanh_f(ct);
+        const float dct = dh * ov * (1.f - tc * tc) + dc[i];
+        dO = dh * tc * ov * (1.f - ov);
+        di = dct * gv * iv * (1.f - iv);
+        dg = dct * iv * (1.f - gv * gv);
+        df = dct * cp * fv * (1.f - fv);
+        dc[i] = dct * fv;
+      }
+      store4<T>(Abuf + prow * RSA + (u0 + i) * 4, di, dg, df, dO);
+    }
+  };
+  // own half of the dgates tile: columns [cu*768, +768) of Abuf -> partner (write-through, drained, flagged)
+  auto publish = [&](int layer, int ep) {
+    const int base = ((layer * 2 + (ep & 1)) * 2 + cu) * XSL * 2;
+    for (int ch = tid; ch < HALF_CH; ch += NT) {
+      const int r = ch / (CB_KC / 8), cc = ch % (CB_KC / 8);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Abuf + r * RSA + cu * CB_KC + cc * 8);
+      store_sc1_b128(xr, base + ch * 16, v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // ... and -> dgT (transposed, for the weight-gradient GEMMs).  Issued AFTER the hand-off so that the publish drain
+  // does not wait for these scattered stores; nothing in the kernel reads them.
+  auto store_T = [&](T* dgT, int t) {
+    const size_t cbase = (size_t)t * a.Np + row0;
+    const bool full = row0 + MC <= N;
+    for (int kl = tid; kl < CB_KC; kl += NT) {
+      const int k = cu * CB_KC + kl;
+      T* dst = dgT + (size_t)k * R + cbase;
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < MC / 8; ++i) {                 // 8 rows = one 16-byte store
+          uint4 w;
+          w.x = (uint32_t)Abuf[(8 * i + 0) * RSA + k] | ((uint32_t)Abuf[(8 * i + 1) * RSA + k] << 16);
+          w.y = (uint32_t)Abuf[(8 * i + 2) * RSA + k] | ((uint32_t)Abuf[(8 * i + 3) * RSA + k] << 16);
+          w.z = (uint32_t)Abuf[(8 * i + 4) * RSA + k] | ((uint32_t)Abuf[(8 * i + 5) * RSA + k] << 16);
+          w.w = (uint32_t)Abuf[(8 * i + 6) * RSA + k] | ((uint32_t)Abuf[(8 * i + 7) * RSA + k] << 16);
+          reinterpret_cast<uint4*>(dst)[i] = w;
+        }
+      } else {
+#pragma unroll 1
+        for (int r = 0; r < MC; ++r)
+          if (row0 + r < N) dst[r] = Abuf[r * RSA + k];
+      }
+    }
+  };
+  auto consume = [&](int layer, int ep) {
+    if (wave == 0) {
+      if (lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > SPIN_LIMIT) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    const int base = ((layer * 2 + (ep & 1)) * 2 + pcu) * XSL * 2;
+    for (int ch = tid; ch < HALF_CH; ch += NT) {
+      const int r = ch / (CB_KC / 8), cc = ch % (CB_KC / 8);
+      *reinterpret_cast<u32x4*>(Abuf + r * RSA + pcu * CB_KC + cc * 8) = load_sc1_b128(xr, base + ch * 16);
+    }
+  };
+
+  Saved sv2, sv1;
+  fetch(sv2, g2, c2, dh2, a.Tn - 1);
+  const int kown0 = cu * (CB_KC / 32), kpar0 = pcu * (CB_KC / 32), khalf = CB_KC / 32;   // 24 k-steps per half
+
+#pragma unroll 1
+  for (int t = a.Tn - 1; t >= 0; --t) {
+    const int ep = a.Tn - t;
+    // ---------------- layer 2
+    cell_bwd(sv2, dhrec2, true, dc2, t);
+    __syncthreads();
+    publish(1, ep);
+    fetch(sv1, g1, c1, nullptr, t);          // layer-1 state of this step: lands during the layer-2 GEMM
+    store_T(dg2T, t);
+    {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc[s][0] = acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      cb_gemm<2>(acc, a_lane, kown0, kown0 + khalf, wr2, cu, wave, lane, RSA);      // own K half: no waiting
+      consume(1, ep);
+      __syncthreads();
+      cb_gemm<2>(acc, a_lane, kpar0, kpar0 + khalf, wr2, cu, wave, lane, RSA);
+      // slot 0: d h1_t (from layer 2) for units 16*wave+n of this CU; slot 1: d h2_{t-1}
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 16 * mt + 4 * q + j;
+          dh1buf[r * HC + 16 * wave + n] += acc[0][mt][j];
+          dhrec2[r * HC + 16 * wave + n] = acc[1][mt][j];
+        }
+    }
+    __syncthreads();
+    // ---------------- layer 1
+    cell_bwd(sv1, dh1buf, false, dc1, t);
+    __syncthreads();
+    publish(0, ep);
+    fetch(sv2, g2, c2, dh2, t - 1);          // layer-2 state of the next (earlier) step
+    store_T(dg1T, t);
+    {
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc[s][0] = acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool has_dx = wave < 2;        // slot 1 of waves 0,1 = this CU's 32 columns of d x
+      if (has_dx) cb_gemm<2>(acc, a_lane, kown0, kown0 + khalf, wr1, cu, wave, lane, RSA);
+      else cb_gemm<1>(acc, a_lane, kown0, kown0 + khalf, wr1, cu, wave, lane, RSA);
+      consume(0, ep);
+      __syncthreads();
+      if (has_dx) cb_gemm<2>(acc, a_lane, kpar0, kpar0 + khalf, wr1, cu, wave, lane, RSA);
+      else cb_gemm<1>(acc, a_lane, kpar0, kpar0 + khalf, wr1, cu, wave, lane, RSA);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 16 * mt + 4 * q + j;
+          dh1buf[r * HC + 16 * wave + n] = acc[0][mt][j];                    // d h1_{t-1} (recurrent)
+          if (has_dx && row0 + r < N)
+            dx[((size_t)t * N + row0 + r) * KX + cu * 32 + 16 * wave + n] = f2bf(acc[1][mt][j]);
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// packed backward weights for the cooperative kernel: element (cu, wave, kk, slot, lane l, j)
+//   k = 32*kk + 8*(l>>4) + j = u*4 + g'  (g' in i,g,f,o -> torch block {0,2,1,3}[g'])
+//   layer 2: slot 0 -> input feature h1 unit cu*192 + 16*wave + (l&15);  slot 1 -> h2 unit (same index)
+//   layer 1: slot 0 -> h1 unit (W_hh);  slot 1 -> x column cu*32 + 16*wave + (l&15) for wave < 2 (W_ih, col < I), else 0
+__global__ void lstm_coop_pack_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, bf16_t* __restrict__ out,
+                                          int I, int layer) {
+  const size_t total = (size_t)CB_G * CB_NW * CB_NK * 2 * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = e & 7, l = (e >> 3) & 63;
+    size_t f = e >> 9;
+    const int slot = f & 1; f >>= 1;
+    const int kk = f % CB_NK; f /= CB_NK;
+    const int wave = f % CB_NW;
+    const int cu = (int)(f / CB_NW);
+    const int k = 32 * kk + 8 * (l >> 4) + j;
+    const int u = k >> 2, gp = k & 3;
+    const int tg = gp == 0 ? 0 : (gp == 1 ? 2 : (gp == 2 ? 1 : 3));
+    const int row = tg * CB_H + u;
+    const int unit = cu * CB_HC + 16 * wave + (l & 15);
+    float v = 0.f;
+    if (layer == 2) {
+      v = slot == 0 ? w_ih[(size_t)row * CB_H + unit] : w_hh[(size_t)row * CB_H + unit];
+    } else {
+      if (slot == 0) v = w_hh[(size_t)row * CB_H + unit];
+      else if (wave < 2) {
+        const int col = cu * 32 + 16 * wave + (l & 15);
+        if (col < I) v = w_ih[(size_t)row * I + col];
+      }
+    }
+    out[e] = f2bf(v);
   }
 }
 
@@ -403,6 +709,44 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
   if (mtile == 2) return launch_coop<bf16_t, 2, 2, false>(a, (size_t)xch_bytes, s);
   if (mtile == 5) return launch_coop<bf16_t, 2, 5, false>(a, (size_t)xch_bytes, s);
   return NPPC_EUNSUPPORTED;
+}
+
+// cooperative backward (bf16, H = 384, I <= 64): packed weights of nppc_lstm2_coop_bwd_pack; xch holds
+// clusters*2*2*2*32*768 bf16, flags clusters*4 + 4 u32 (zeroed by the launcher)
+int nppc_lstm2_coop_bwd_packed_elems(long* n) {
+  *n = (long)CB_G * CB_NW * CB_NK * 2 * 512;
+  return NPPC_OK;
+}
+
+int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                             void* wb2, void* stream) {
+  if (!w_ih0 || !w_hh0 || !w_ih1 || !w_hh1 || !wb1 || !wb2 || I > CB_KX) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_coop_pack_bwd_kernel, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (bf16_t*)wb1, I, 1);
+  hipLaunchKernelGGL(lstm_coop_pack_bwd_kernel, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (bf16_t*)wb2, CB_H, 2);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
+                        const void* wb2, void* dx, void* dg1T, void* dg2T, void* xch, long xch_bytes, unsigned* flags, long N,
+                        int Tn, long Np, int n_cu, void* stream) {
+  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1T || !dg2T || !xch || !flags || N <= 0 || Tn <= 0 || Np < N)
+    return NPPC_EBADARG;
+  const int clusters = (int)((N + CB_MC - 1) / CB_MC);
+  if (clusters * CB_G > n_cu) return NPPC_EUNSUPPORTED;      // every workgroup of a cluster must be resident
+  if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * CB_KC * 2) return NPPC_EBADARG;
+  CoopBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, xch, flags, N, Tn, Np, clusters};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr size_t smem = (size_t)CB_MC * (CB_K4 + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4;
+  static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm2_coop_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem) != hipSuccess)
+    return NPPC_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  hipLaunchKernelGGL(lstm2_coop_bwd_kernel, dim3(clusters * CB_G), dim3(CB_NT), smem, s, a);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
 }
 
 }  // extern "C"

@@ -486,3 +486,139 @@ extern "C" int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
+
+// =====================================================================================================
+// TN split-K GEMM for weight gradients on row-major operands (no transposed copies anywhere):
+//   C_slab[z][m][n] (fp32) = sum_{r in slice z} A[r][m] * B[r][n],   A [R][lda], B [R][ldb] bf16, rows = (t, sequence).
+// Tiles are staged row-major in LDS ([64 r][128 cols]); MFMA fragments need 8 consecutive r per lane for a fixed
+// column, which ds_read_b64_tr_b16 delivers (a 4x16 block read column-major per 16-lane group, guide T10).
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                               long ldb, float* __restrict__ C, long ldc, long slab_stride,
+                                                               long Rz) {
+  constexpr int BM = 128, BR = 64;
+  constexpr int RSA = BM + 8, RSB = BN + 8;                 // LDS row strides (elements): 16-byte aligned rows
+  constexpr int WN = BN / 2;                                // columns per wave (2x2 waves)
+  constexpr int NJ = WN / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][BR * RSA + BR * RSB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * BM, n0 = (long)blockIdx.y * BN;
+  const long rbase = (long)blockIdx.z * Rz;
+  const bf16_t* Ab = A + rbase * lda + m0;
+  const bf16_t* Bb = B + rbase * ldb + n0;
+  float* Cz = C + (size_t)blockIdx.z * slab_stride;
+
+  // staging: A tile 64 rows x 16 chunks (16 B) = 1024 chunks -> 4 per thread; B tile 64 x BN/8 chunks
+  constexpr int ACH = BM / 8, BCH = BN / 8;
+  constexpr int NA = BR * ACH / 256, NB = BR * BCH / 256;
+  static_assert(NA == 4 && (NB == 4 || NB == 2), "staging slots are named registers");
+  // chunk (row, c) of slot i: idx = tid + 256*i.  A: row = idx/16 -> rows (tid>>4) + 16*i, c = tid & 15.
+  const int arow = tid / ACH, ac = tid % ACH, brow = tid / BCH, bc = tid % BCH;
+  constexpr int ASTEP = 256 / ACH, BSTEP = 256 / BCH;                                    // rows between slots
+  const bf16_t* gA = Ab + (long)arow * lda + ac * 8;
+  const bf16_t* gB = Bb + (long)brow * ldb + bc * 8;
+  const int sA = arow * RSA + ac * 8, sB = BR * RSA + brow * RSB + bc * 8;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = {}, rb3 = {};
+#define TN_GLOAD(r0)                                                            \
+  ra0 = *reinterpret_cast<const uint4*>(gA + ((r0) + 0 * ASTEP) * lda);         \
+  ra1 = *reinterpret_cast<const uint4*>(gA + ((r0) + 1 * ASTEP) * lda);         \
+  ra2 = *reinterpret_cast<const uint4*>(gA + ((r0) + 2 * ASTEP) * lda);         \
+  ra3 = *reinterpret_cast<const uint4*>(gA + ((r0) + 3 * ASTEP) * lda);         \
+  rb0 = *reinterpret_cast<const uint4*>(gB + ((r0) + 0 * BSTEP) * ldb);         \
+  rb1 = *reinterpret_cast<const uint4*>(gB + ((r0) + 1 * BSTEP) * ldb);         \
+  if (NB == 4) {                                                                \
+    rb2 = *reinterpret_cast<const uint4*>(gB + ((r0) + 2 * BSTEP) * ldb);       \
+    rb3 = *reinterpret_cast<const uint4*>(gB + ((r0) + 3 * BSTEP) * ldb);       \
+  }
+#define TN_LSTORE(buf)                                                          \
+  *reinterpret_cast<uint4*>(&lds[buf][sA + 0 * ASTEP * RSA]) = ra0;             \
+  *reinterpret_cast<uint4*>(&lds[buf][sA + 1 * ASTEP * RSA]) = ra1;             \
+  *reinterpret_cast<uint4*>(&lds[buf][sA + 2 * ASTEP * RSA]) = ra2;             \
+  *reinterpret_cast<uint4*>(&lds[buf][sA + 3 * ASTEP * RSA]) = ra3;             \
+  *reinterpret_cast<uint4*>(&lds[buf][sB + 0 * BSTEP * RSB]) = rb0;             \
+  *reinterpret_cast<uint4*>(&lds[buf][sB + 1 * BSTEP * RSB]) = rb1;             \
+  if (NB == 4) {                                                                \
+    *reinterpret_cast<uint4*>(&lds[buf][sB + 2 * BSTEP * RSB]) = rb2;           \
+    *reinterpret_cast<uint4*>(&lds[buf][sB + 3 * BSTEP * RSB]) = rb3;           \
+  }
+  // transposed fragment: 8 consecutive r (starting r0 + 8*qq) of column (col0 + lane&15)
+  auto tfrag = [&](const bf16_t* tile, int rs, int r0, int col0) -> bf16x8 {
+    const int q4 = i16 >> 2, p4 = i16 & 3;                  // lane 4q+p of the group supplies row q, columns 4p..4p+3
+    const bf16_t* base = tile + (r0 + 8 * qq + q4) * rs + col0 + 4 * p4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * rs));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long nstage = Rz / BR;
+  TN_GLOAD(0)
+  TN_LSTORE(0)
+  __syncthreads();
+  for (long s = 0; s < nstage; ++s) {
+    const int buf = (int)(s & 1);
+    if (s + 1 < nstage) { TN_GLOAD((s + 1) * BR) }
+    const bf16_t* ta = lds[buf];
+    const bf16_t* tb = lds[buf] + BR * RSA;
+#pragma unroll
+    for (int ks = 0; ks < BR / 32; ++ks) {
+      bf16x8 af[4], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tfrag(ta, RSA, 32 * ks, wm * 64 + 16 * i);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = tfrag(tb, RSB, 32 * ks, wn * WN + 16 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+    }
+    if (s + 1 < nstage) { TN_LSTORE(buf ^ 1) }
+    __syncthreads();
+  }
+#undef TN_GLOAD
+#undef TN_LSTORE
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + 16 * i + 4 * qq + r;
+        const long col = n0 + wn * WN + 16 * j + i16;
+        Cz[row * ldc + col] = acc[i][j][r];
+      }
+}
+
+}  // namespace
+
+// C_slab[z] [M][N] = A[rows slice z][M]^T * B[rows slice z][N]  (bf16 operands, fp32 slabs).  M % 128 == 0,
+// N % 64 == 0, R % (64*ksplit) == 0, lda/ldb multiples of 8.
+extern "C" int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
+                                   int ksplit, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1) return NPPC_EBADARG;
+  if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (N % 128 == 0) {
+    dim3 grid(M / 128, N / 128, ksplit);
+    hipLaunchKernelGGL(gemm_tn_tiled_kernel<128>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
+                       (long)M * ldc, R / ksplit);
+  } else {
+    dim3 grid(M / 128, N / 64, ksplit);
+    hipLaunchKernelGGL(gemm_tn_tiled_kernel<64>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
+                       (long)M * ldc, R / ksplit);
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}

@@ -71,6 +71,9 @@ SIGS = {
     "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
     "nppc_lstm2_coop_plan": [I, I, L, I, I, PI, PI, PI],
     "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P],
+    "nppc_lstm2_coop_bwd_packed_elems": [PL],
+    "nppc_lstm2_coop_bwd_pack": [P, P, P, P, I, P, P, P],
+    "nppc_lstm2_bwd_coop": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, L, I, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
     "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
     "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
@@ -85,6 +88,7 @@ SIGS = {
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],
+    "nppc_gemm_tn_splitk": [P, L, P, L, P, L, I, I, L, I, P],
     "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],

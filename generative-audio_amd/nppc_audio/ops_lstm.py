@@ -139,14 +139,22 @@ class PackedLSTMBwd:
         dt = H.dtype_of(prec)
         self.wb1 = torch.empty(n1.value, dtype=dt, device=device)
         self.wb2 = torch.empty(n2.value, dtype=dt, device=device)
+        self.coop = prec == H.PREC_BF16 and Hd == 384 and I <= 64
+        if self.coop:
+            nc = ctypes.c_long()
+            H.call("nppc_lstm2_coop_bwd_packed_elems", ctypes.byref(nc))
+            self.cwb1 = torch.empty(nc.value, dtype=dt, device=device)
+            self.cwb2 = torch.empty(nc.value, dtype=dt, device=device)
 
     def pack(self, w_ih0, w_hh0, w_ih1, w_hh1):
         ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, w_ih1, w_hh1)]
         H.call("nppc_lstm2_pack_weights_bwd", self.prec, *ws, self.I, self.Hd, self.wb1, self.wb2, H.stream())
+        if self.coop:
+            H.call("nppc_lstm2_coop_bwd_pack", *ws, self.I, self.cwb1, self.cwb2, H.stream())
         return self
 
 
-def lstm2_backward(saved, dh2, packed_bwd, kx):
+def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
     """saved = lstm2_forward(train=True) dict; dh2 [Tn][N][H] -> dx [Tn][N][kx], dg1T, dg2T [4H][Tn*N]
     (transposed gate gradients, row k = unit*4 + gate in (i,g,f,o) order)."""
     Tn, N, Hd = saved["h2"].shape
@@ -157,6 +165,15 @@ def lstm2_backward(saved, dh2, packed_bwd, kx):
     Kr = (4 * Hd + 127) // 128 * 128   # row padding so the tensors can be GEMM A-operands (R % 128 == 0)
     dg1T = workspace(tag + ("dg1T",), (Kr, Tn * Np), dt, dev, zero=True)
     dg2T = workspace(tag + ("dg2T",), (Kr, Tn * Np), dt, dev, zero=True)
+    use_coop = (COOP if coop is None else coop) and packed_bwd.coop and ((N + 31) // 32) * 2 <= _n_cu()
+    if use_coop:
+        ncl = (N + 31) // 32
+        xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 768,), dt, dev)
+        flags = workspace(tag + ("coop_flags",), (ncl * 4 + 4,), torch.int32, dev, zero=True)
+        _timed(("lstm2_bwd_coop_g2", 1, N, Tn, 2), lambda: H.call(
+            "nppc_lstm2_bwd_coop", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.cwb1, packed_bwd.cwb2,
+            dx, dg1T, dg2T, xch, xch.numel() * xch.element_size(), flags, N, Tn, Np, _n_cu(), H.stream()))
+        return dx, dg1T, dg2T
     _timed(("lstm2_bwd", 1, N, Tn, 1), lambda: H.call(
         "nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
         packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream()))

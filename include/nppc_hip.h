@@ -67,6 +67,10 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
  * 128x128 tiles; M, N multiples of 128, K a multiple of (64 bf16 | 32 fp32) * ksplit */
 int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long K,
                         int ksplit, void* stream);
+/* the same product on ROW-major operands (no transposed copies): C_slab[z][M][N] = A[rows z][M]^T * B[rows z][N], bf16,
+ * LDS tiles read back with ds_read_b64_tr_b16; M % 128 == 0, N % 64 == 0, R % (64*ksplit) == 0 */
+int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
+                        void* stream);
 int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
 int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
                     const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
@@ -121,6 +125,13 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
                         const float* bias1, const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1,
                         void* c2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, long Np,
                         void* stream);
+/* cooperative backward (bf16, H = 384): CU pairs share 32 sequences, each owns half the hidden units / output columns */
+int nppc_lstm2_coop_bwd_packed_elems(long* n);
+int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                             void* wb2, void* stream);
+int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
+                        const void* wb2, void* dx, void* dg1T, void* dg2T, void* xch, long xch_bytes, unsigned* flags, long N,
+                        int Tn, long Np, int n_cu, void* stream);
 int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
 int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
                                 int I, int H, void* wb1, void* wb2, void* stream);

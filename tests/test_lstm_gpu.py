@@ -180,3 +180,29 @@ def test_cooperative_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, t
     for k in coop:
         d = (coop[k].float() - single[k].float()).abs().max().item()
         assert d < 2e-2, (k, d)      # same bf16 arithmetic, different accumulation split
+
+
+@pytest.mark.parametrize("N,Tn", [(40, 11), (96, 7), (333, 5)])
+def test_cooperative_backward_matches_single_workgroup_kernel(N, Tn):
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_forward, lstm2_backward
+    I, Hd = 34, 384
+    P = _weights(I, Hd, 2)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in names])
+    pb = PackedLSTMBwd(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")])
+    g = torch.Generator().manual_seed(N + Tn)
+    xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
+    xt[:, :, :I] = torch.randn(Tn, N, I, generator=g).to(dev)
+    dh2 = torch.randn(Tn, N, Hd, generator=g).to(dev).to(torch.bfloat16)
+    saved = lstm2_forward(xt, pk, True, 1)
+    a = [t.clone() for t in lstm2_backward(saved, dh2, pb, pk.kx, coop=True)]
+    assert ops_lstm.coop_timeouts() == 0
+    b = [t.clone() for t in lstm2_backward(saved, dh2, pb, pk.kx, coop=False)]
+    torch.cuda.synchronize()
+    for name, x, y in zip(("dx", "dg1T", "dg2T"), a, b):
+        x, y = x.float(), y.float()
+        d = (x - y).abs().max().item() / (y.abs().max().item() + 1e-30)
+        assert d < 2e-2, (name, d)
