@@ -21,8 +21,8 @@ struct LstmFwdArgs {
   const float* bias1; // [4][H]  b_ih + b_hh
   const float* bias2;
   void* h2;           // [Tn][N][H]  T   (always written)
-  void* h1T;          // [H][Tn*N]   T   (train; transposed copies for the weight-gradient GEMMs)
-  void* h2T;
+  void* h1;           // [Tn][N][H]  T   (train: layer-1 hidden state, input of the weight-gradient GEMMs)
+  void* h2T_unused;
   void* g1;           // [Tn][N][H][4] T (train; post-activation, order i,g,f,o)
   void* g2;
   void* c1;           // [Tn][N][H]  T   (train)
@@ -30,7 +30,7 @@ struct LstmFwdArgs {
   long N;
   int Tn;
   int KX;
-  long Np;            // transposed outputs: column of (t, n) is t*Np + n, row stride Tn*Np (Np >= N, pad columns stay zero)
+  long unused_np;
 };
 
 // One gate PAIR (gp = 0: i,g   gp = 1: f,o) of one layer:  acc[ub][s][mt] += A[16mt.., koff..] * Wpair
@@ -102,7 +102,7 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
                                            __amdgpu_buffer_rsrc_t wr, int wave_boff, int pair_bstride, int lane,
                                            T* lds_h /* + 4q*RS + ubase+n */,
                                            long rbase /* row0 + 4q */, long N, size_t ebase, T* gates_out, T* c_out,
-                                           T* h_out, T* hT_out /* + unit*R + t*N + rbase */, size_t R) {
+                                           T* h_out) {
   f32x4 ig[UB][MT];
   f32x4 sv_i[SAVE ? UB : 1][SAVE ? MT : 1], sv_g[SAVE ? UB : 1][SAVE ? MT : 1];   // post-activation i, g kept for one store
   {
@@ -155,7 +155,6 @@ __device__ __forceinline__ void layer_step(const float (&bias)[UB][4], f32x4 (&c
           if (SAVE) {
             c_out[e] = from_f32<T>(cn);
             store_gates<T>(gates_out + e * 4, sv_i[ub][mt][j], sv_g[ub][mt][j], fv, ov);
-            hT_out[(size_t)(16 * ub) * R + 16 * mt + j] = from_f32<T>(hn);   // rows j = 0..3 are adjacent: 4 x T per lane
           }
         }
       }
@@ -225,10 +224,8 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
   const T* a_lane = lds + n * RS + 8 * q;
   T* hw_lane = lds + 4 * q * RS + ubase_n;
   const long rbase = row0 + 4 * q;
-  T* h1T = reinterpret_cast<T*>(a.h1T);
-  T* h2T = reinterpret_cast<T*>(a.h2T);
+  T* h1o = reinterpret_cast<T*>(a.h1);
   T* h2o = reinterpret_cast<T*>(a.h2);
-  const size_t Rtot = (size_t)a.Tn * a.Np;
   T* g1o = reinterpret_cast<T*>(a.g1);
   T* g2o = reinterpret_cast<T*>(a.g2);
   T* c1o = reinterpret_cast<T*>(a.c1);
@@ -256,9 +253,8 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
       }
     }
     // layer 1: [x_t | h1_{t-1}]  ->  h1_t into the other half
-    const size_t tbase = (size_t)ubase_n * Rtot + (size_t)t * a.Np + rbase;
-    layer_step<T, UB, MT, RS, H, TRAIN, false, DEPTH>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
-                                               g1o, c1o, nullptr, TRAIN ? h1T + tbase : nullptr, Rtot);
+    layer_step<T, UB, MT, RS, H, TRAIN, TRAIN, DEPTH>(b1, c1, a_lane + cur, nk1, wr1, wb1, ps1, lane, hw_lane + oth + KX, rbase, N, ebase,
+                                               g1o, c1o, h1o);
     if (more) {
 #pragma unroll
       for (int u = 0; u < XCH; ++u) {
@@ -272,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) void lstm2_fwd_kernel(LstmFwdArgs a) {
     __syncthreads();
     // layer 2: [h1_t | h2_{t-1}] (other half)  ->  h2_t into this half
     layer_step<T, UB, MT, RS, H, TRAIN, true, DEPTH>(b2, c2, a_lane + oth + KX, nk2, wr2, wb2, ps2, lane, hw_lane + cur + KX + HP, rbase, N,
-                                              ebase, g2o, c2o, h2o, TRAIN ? h2T + tbase : nullptr, Rtot);
+                                              ebase, g2o, c2o, h2o);
     // One barrier per step suffices: what step t+1 writes before its barrier (h1 -> half_p.H1,
     // x_{t+2} -> half_p.X, and after it h2 -> half_{1-p}.H2) was last READ before the barrier above
     // (layer 1 of step t) or in layer 2 of step t, which every wave finishes before it can reach
@@ -401,14 +397,13 @@ int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, co
 }
 
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                   const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
-                   int Tn, int I, int H, long Np, void* stream) {
+                   const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2, long N, int Tn, int I,
+                   int H, void* stream) {
   HCfg c;
   if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
   if (N <= 0 || Tn <= 0 || !x || !wp1 || !wp2 || !h2) return NPPC_EBADARG;
-  if (train && (!h1T || !h2T || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
-  if (train && Np < N) return NPPC_EBADARG;
-  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, N, Tn, kx_for(I, H), Np};
+  if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
+  LstmFwdArgs a{x, wp1, wp2, bias1, bias2, h2, h1, nullptr, g1, g2, c1, c2, N, Tn, kx_for(I, H), N};
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16) {
     if (H == 384) return dispatch_fwd<bf16_t, 3, 8, 64>(a, mtile, train, s);
@@ -437,8 +432,8 @@ struct LstmBwdArgs {
   const void* dh2;                  // [Tn][N][H]
   const void* wb1; const void* wb2; // packed backward weights
   void* dx;                         // [Tn][N][KX]
-  void* dg1T; void* dg2T;           // [4H][Tn*Np]  column of (t, n) = t*Np + n
-  long N; int Tn; long Np;
+  void* dg1; void* dg2;             // [Tn][N][4H]  gate gradients, column k = unit*4 + gate (i,g,f,o)
+  long N; int Tn;
 };
 
 template <typename T, int TPW>
@@ -493,7 +488,6 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long row0 = (long)blockIdx.x * M;
   const long N = a.N;
-  const long R = (long)a.Tn * a.Np;
   for (int i = tid; i < 2 * M * HP; i += NT) dh1buf[i] = 0.f;
   for (int i = tid; i < M * RSA; i += NT) Abuf[i] = from_f32<T>(0.f);
 
@@ -509,8 +503,8 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
   const T* c2 = reinterpret_cast<const T*>(a.c2);
   const T* dh2 = reinterpret_cast<const T*>(a.dh2);
   T* dx = reinterpret_cast<T*>(a.dx);
-  T* dg1T = reinterpret_cast<T*>(a.dg1T);
-  T* dg2T = reinterpret_cast<T*>(a.dg2T);
+  T* dg1T = reinterpret_cast<T*>(a.dg1);
+  T* dg2T = reinterpret_cast<T*>(a.dg2);
   const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wb1, (unsigned)(NW * nk * TPW1 * 512 * sizeof(T)));
   const __amdgpu_buffer_rsrc_t wr2 = make_rsrc(a.wb2, (unsigned)(NW * nk * TPW2 * 512 * sizeof(T)));
   const int wb1 = wave * (nk * TPW1 * 512 * (int)sizeof(T));
@@ -582,23 +576,14 @@ __global__ __launch_bounds__(NW * 64) void lstm2_bwd_kernel(LstmBwdArgs a) {
       store_gates<T>(ap, di, dg, df, dO);
     }
   };
-  // transposed copy of the dgates tile: dgT[k][t*Np + row0 + r], r < 16  (16 rows = one 32/64-byte run per k)
-  auto write_T = [&](T* dgT, int t) {
-    const size_t cbase = (size_t)t * a.Np + row0;
-    const bool full = row0 + M <= N;
-    for (int k = tid; k < K4; k += NT) {
-      T* dst = dgT + (size_t)k * R + cbase;
-      T v[M];
-#pragma unroll
-      for (int r = 0; r < M; ++r) v[r] = Abuf[r * RSA + k];
-      if (full) {
-#pragma unroll
-        for (int i = 0; i < M * (int)sizeof(T) / 16; ++i) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(v)[i];
-      } else {
-#pragma unroll
-        for (int r = 0; r < M; ++r)
-          if (row0 + r < N) dst[r] = v[r];
-      }
+  // row-major copy of the dgates tile for the weight-gradient GEMMs: dg[(t*N + row)][4H] (fully coalesced rows)
+  auto write_T = [&](T* dg, int t) {
+    constexpr int CPR = K4 / VEC;                                      // 16-byte chunks per row
+    for (int ch = tid; ch < M * CPR; ch += NT) {
+      const int r = ch / CPR, cc = ch % CPR;
+      if (row0 + r < N)
+        *reinterpret_cast<uint4*>(dg + ((size_t)t * N + row0 + r) * K4 + cc * VEC) =
+            *reinterpret_cast<const uint4*>(Abuf + r * RSA + cc * VEC);
     }
   };
 
@@ -748,13 +733,12 @@ int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0
 }
 
 int nppc_lstm2_bwd(int prec, const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2,
-                   const void* wb1, const void* wb2, void* dx, void* dg1T, void* dg2T, long N, int Tn, int I, int H,
-                   long Np, void* stream) {
+                   const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, long N, int Tn, int I, int H,
+                   void* stream) {
   HCfg c;
   if (!hidden_cfg(H, &c)) return NPPC_EUNSUPPORTED;
-  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1T || !dg2T || N <= 0 || Tn <= 0) return NPPC_EBADARG;
-  if (Np < N) return NPPC_EBADARG;
-  LstmBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, N, Tn, Np};
+  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1 || !dg2 || N <= 0 || Tn <= 0) return NPPC_EBADARG;
+  LstmBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, N, Tn};
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16) {
     if (H == 384) return launch_bwd<bf16_t, 3, 8, 64>(a, s);

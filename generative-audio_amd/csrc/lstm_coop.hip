@@ -25,10 +25,10 @@ struct CoopArgs {
   const float* bias1;
   const float* bias2;
   void* h2;           // [Tn][N][H]
-  void* h1T; void* h2T; void* g1; void* g2; void* c1; void* c2;   // train
+  void* h1; void* g1; void* g2; void* c1; void* c2;   // train: h1 [Tn][N][H] like h2
   void* xch;          // [clusters][2 layers][2 parities][G][MC][HC]  exchange slices
   unsigned* flags;    // [clusters][2 layers][G] epochs, then 1 timeout word; zeroed before every launch
-  long N; int Tn; long Np; int clusters;
+  long N; int Tn; int clusters;
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -167,14 +167,12 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 
   const T* a_lane = lds + n * RS + 8 * q;
   T* hw_lane = lds + 4 * q * RS + unit_n;                         // + OH1/OH2 + (16mt+j)*RS : own unit column
-  T* h1T = reinterpret_cast<T*>(a.h1T);
-  T* h2T = reinterpret_cast<T*>(a.h2T);
+  T* h1o = reinterpret_cast<T*>(a.h1);
   T* h2o = reinterpret_cast<T*>(a.h2);
   T* g1o = reinterpret_cast<T*>(a.g1);
   T* g2o = reinterpret_cast<T*>(a.g2);
   T* c1o = reinterpret_cast<T*>(a.c1);
   T* c2o = reinterpret_cast<T*>(a.c2);
-  const size_t Rtot = (size_t)a.Tn * a.Np;
 
   // publish this CU's h slice (already in LDS columns [hoff + cu*HC, +HC)) of layer `layer` for epoch `ep`
   auto publish = [&](int layer, int hoff, int ep) {
@@ -223,7 +221,6 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     const int p = t & 1;
     const int ep = t + 1;
     const size_t ebase = ((size_t)t * N + rbase) * H + unit_n;
-    const size_t tbase = (size_t)unit_n * Rtot + (size_t)t * a.Np + rbase;
     uint4 xrg[XCH];
     const bool more = t + 1 < a.Tn;
     if (more) {
@@ -278,7 +275,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
             c1o[e] = from_f32<T>(cn);
             store4<T>(g1o + e * 4, iv1[mt][j], gv1[mt][j], fv, ov);
-            h1T[tbase + 16 * mt + j] = from_f32<T>(hn1[mt][j]);
+            h1o[e] = from_f32<T>(hn1[mt][j]);
           }
         }
     }
@@ -347,7 +344,6 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
             if (TRAIN) {
               c2o[e] = from_f32<T>(cn);
               store4<T>(g2o + e * 4, iv2[mt][j], gv2[mt][j], fv, ov);
-              h2T[tbase + 16 * mt + j] = from_f32<T>(hn2[mt][j]);
             }
           }
         }
@@ -370,10 +366,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 struct CoopBwdArgs {
   const void* g1; const void* g2; const void* c1; const void* c2; const void* dh2;
   const void* wb1; const void* wb2;   // packed by lstm_coop_pack_bwd_kernel
-  void* dx; void* dg1T; void* dg2T;
+  void* dx; void* dg1; void* dg2;     // dg [Tn][N][4H]
   void* xch;                          // [clusters][2 layers][2 parities][2 CUs][32][768]
   unsigned* flags;                    // [clusters][2 layers][2] epochs + timeout word
-  long N; int Tn; long Np; int clusters;
+  long N; int Tn; int clusters;
 };
 
 constexpr int CB_G = 2, CB_MC = 32, CB_H = 384, CB_HC = 192, CB_KX = 64, CB_NW = 12, CB_NT = CB_NW * 64;
@@ -434,7 +430,6 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
   const int cluster = blockIdx.x / CB_G, cu = blockIdx.x % CB_G, pcu = 1 - cu;
   const long row0 = (long)cluster * MC;
   const long N = a.N;
-  const long R = (long)a.Tn * a.Np;
   for (int i = tid; i < 2 * MC * HC; i += NT) dh1buf[i] = 0.f;
   for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
 
@@ -450,8 +445,8 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
   const T* c2 = reinterpret_cast<const T*>(a.c2);
   const T* dh2 = reinterpret_cast<const T*>(a.dh2);
   T* dx = reinterpret_cast<T*>(a.dx);
-  T* dg1T = reinterpret_cast<T*>(a.dg1T);
-  T* dg2T = reinterpret_cast<T*>(a.dg2T);
+  T* dg1T = reinterpret_cast<T*>(a.dg1);
+  T* dg2T = reinterpret_cast<T*>(a.dg2);
   constexpr unsigned WB = CB_G * CB_NW * CB_NK * 2 * 512 * 2;
   const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wb1, WB), wr2 = make_rsrc(a.wb2, WB);
   constexpr int XSL = MC * CB_KC;                                                   // elements of one dgates half
@@ -506,29 +501,14 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // ... and -> dgT (transposed, for the weight-gradient GEMMs).  Issued AFTER the hand-off so that the publish drain
-  // does not wait for these scattered stores; nothing in the kernel reads them.
-  auto store_T = [&](T* dgT, int t) {
-    const size_t cbase = (size_t)t * a.Np + row0;
-    const bool full = row0 + MC <= N;
-    for (int kl = tid; kl < CB_KC; kl += NT) {
-      const int k = cu * CB_KC + kl;
-      T* dst = dgT + (size_t)k * R + cbase;
-      if (full) {
-#pragma unroll
-        for (int i = 0; i < MC / 8; ++i) {                 // 8 rows = one 16-byte store
-          uint4 w;
-          w.x = (uint32_t)Abuf[(8 * i + 0) * RSA + k] | ((uint32_t)Abuf[(8 * i + 1) * RSA + k] << 16);
-          w.y = (uint32_t)Abuf[(8 * i + 2) * RSA + k] | ((uint32_t)Abuf[(8 * i + 3) * RSA + k] << 16);
-          w.z = (uint32_t)Abuf[(8 * i + 4) * RSA + k] | ((uint32_t)Abuf[(8 * i + 5) * RSA + k] << 16);
-          w.w = (uint32_t)Abuf[(8 * i + 6) * RSA + k] | ((uint32_t)Abuf[(8 * i + 7) * RSA + k] << 16);
-          reinterpret_cast<uint4*>(dst)[i] = w;
-        }
-      } else {
-#pragma unroll 1
-        for (int r = 0; r < MC; ++r)
-          if (row0 + r < N) dst[r] = Abuf[r * RSA + k];
-      }
+  // ... and -> dg (row-major [t*N + row][4H], own 768 columns) for the weight-gradient GEMMs.  Issued AFTER the hand-off
+  // so that the publish drain does not wait for these stores; nothing in the kernel reads them.
+  auto store_T = [&](T* dg, int t) {
+    for (int ch = tid; ch < HALF_CH; ch += NT) {
+      const int r = ch / (CB_KC / 8), cc = ch % (CB_KC / 8);
+      if (row0 + r < N)
+        *reinterpret_cast<u32x4*>(dg + ((size_t)t * N + row0 + r) * CB_K4 + cu * CB_KC + cc * 8) =
+            *reinterpret_cast<const u32x4*>(Abuf + r * RSA + cu * CB_KC + cc * 8);
     }
   };
   auto consume = [&](int layer, int ep) {
@@ -689,14 +669,13 @@ int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, i
 
 // flags: (clusters*2*G + 4) u32; xch: clusters*2*2*G*MC*(H/G) elements.  Same tensor contract as nppc_lstm2_fwd.
 int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
-                        const float* bias1, const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1,
-                        void* c2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, long Np,
-                        void* stream) {
+                        const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                        void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, void* stream) {
   if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4)) return NPPC_EUNSUPPORTED;
   if (!x || !wp1 || !wp2 || !h2 || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
-  if (train && (!h1T || !h2T || !g1 || !g2 || !c1 || !c2 || Np < N)) return NPPC_EBADARG;
+  if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
-  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1T, h2T, g1, g2, c1, c2, xch, flags, N, Tn, Np, (int)((N + MC - 1) / MC)};
+  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC)};
   hipStream_t s = (hipStream_t)stream;
   if (G == 4) {
     if (mtile != 4) return NPPC_EUNSUPPORTED;
@@ -729,14 +708,14 @@ int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float
 }
 
 int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
-                        const void* wb2, void* dx, void* dg1T, void* dg2T, void* xch, long xch_bytes, unsigned* flags, long N,
-                        int Tn, long Np, int n_cu, void* stream) {
-  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1T || !dg2T || !xch || !flags || N <= 0 || Tn <= 0 || Np < N)
+                        const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
+                        int Tn, int n_cu, void* stream) {
+  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1 || !dg2 || !xch || !flags || N <= 0 || Tn <= 0)
     return NPPC_EBADARG;
   const int clusters = (int)((N + CB_MC - 1) / CB_MC);
   if (clusters * CB_G > n_cu) return NPPC_EUNSUPPORTED;      // every workgroup of a cluster must be resident
   if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * CB_KC * 2) return NPPC_EBADARG;
-  CoopBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1T, dg2T, xch, flags, N, Tn, Np, clusters};
+  CoopBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters};
   hipStream_t s = (hipStream_t)stream;
   constexpr size_t smem = (size_t)CB_MC * (CB_K4 + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");

@@ -46,7 +46,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void subband_stage_kernel(const T* __restrict__ src, int ldS, const T* __restrict__ fb,
                                                             int ldF, long strideFb, const float* __restrict__ scale,
                                                             T* __restrict__ x, int B, int F, int Tp, int nb, int G, int Fo,
-                                                            int KX, long Nseq) {
+                                                            int KX, long Nseq, int ones_col) {
   extern __shared__ float sm[];   // [4][F]
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const size_t row = (size_t)b * Tp + t;
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256) void subband_stage_kernel(const T* __restrict_
       float val = 0.f;
       if (j < W) val = sm[reflect_idx(f + j - nb, F)] * sc;
       else if (j < W + 3) val = sm[(j - W + 1) * F + f] * sc;
+      else if (j == W + 3 && ones_col) val = 1.f;   // first padded column: multiplies zero weights in the forward, and
+                                                     // makes its column of dgates^T * x the bias gradient in the backward
       v[i] = from_f32<T>(val);
     }
     T* po = x + ((size_t)t * Nseq + (size_t)bo * Fo + fo) * KX + j0;
@@ -159,8 +161,8 @@ int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ld
 }
 
 int nppc_subband_stage(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* scale,
-                       void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, void* stream) {
-  if (!src || !fb || !scale || !x || B <= 0 || G < 1 || 2 * nb + 4 > KX || KX % 8) return NPPC_EBADARG;
+                       void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, int ones_col, void* stream) {
+  if (!src || !fb || !scale || !x || B <= 0 || G < 1 || 2 * nb + 4 + (ones_col ? 1 : 0) > KX || KX % 8) return NPPC_EBADARG;
   if (B > 1 && !(B > G)) return NPPC_EBADARG;
   const int Geff = B > 1 ? G : 1;                    // the reference applies drop_band only when batch > 1
   const int Fo = Geff <= 1 ? F : (F - F % Geff) / Geff;
@@ -170,10 +172,10 @@ int nppc_subband_stage(int prec, const void* src, int ldS, const void* fb, int l
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(subband_stage_kernel<bf16_t>, grid, dim3(256), sm, s, (const bf16_t*)src, ldS, (const bf16_t*)fb, ldF,
-                       strideFb, scale, (bf16_t*)x, B, F, Tp, nb, Geff, Fo, KX, Nseq);
+                       strideFb, scale, (bf16_t*)x, B, F, Tp, nb, Geff, Fo, KX, Nseq, ones_col);
   else
     hipLaunchKernelGGL(subband_stage_kernel<float>, grid, dim3(256), sm, s, (const float*)src, ldS, (const float*)fb, ldF,
-                       strideFb, scale, (float*)x, B, F, Tp, nb, Geff, Fo, KX, Nseq);
+                       strideFb, scale, (float*)x, B, F, Tp, nb, Geff, Fo, KX, Nseq, ones_col);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

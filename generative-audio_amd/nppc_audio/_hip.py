@@ -68,15 +68,15 @@ PI = ctypes.POINTER(c_i)
 SIGS = {
     "nppc_lstm2_packed_elems": [I, I, PL, PL, PI],
     "nppc_lstm2_pack_weights": [I, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P],
-    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
+    "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "nppc_lstm2_coop_plan": [I, I, L, I, I, PI, PI, PI],
-    "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, L, P],
+    "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P],
     "nppc_lstm2_coop_bwd_packed_elems": [PL],
     "nppc_lstm2_coop_bwd_pack": [P, P, P, P, I, P, P, P],
-    "nppc_lstm2_bwd_coop": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, L, I, P],
+    "nppc_lstm2_bwd_coop": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
     "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
-    "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, P],
+    "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "nppc_stft": [P, P, P, P, I, I, I, I, P],
     "nppc_dropband": [P, P, I, I, I, I, I, P],
     "nppc_cirm_build_compress": [P, P, P, P, P, I, I, I, I, F, P],
@@ -93,7 +93,7 @@ SIGS = {
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],
     "nppc_subband_mean": [I, P, I, P, I, L, P, P, I, I, I, I, I, P],
-    "nppc_subband_stage": [I, P, I, P, I, L, P, P, I, I, I, I, I, I, I, P],
+    "nppc_subband_stage": [I, P, I, P, I, L, P, P, I, I, I, I, I, I, I, I, P],
     "nppc_sb_head": [I, P, P, P, P, L, I, I, I, I, I, P],
     "nppc_gram": [P, P, P, P, P, I, I, L, P],
     "nppc_combine": [P, P, P, P, P, P, P, I, I, L, P],

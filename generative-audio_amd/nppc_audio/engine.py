@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, pick_mtile, workspace
+from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, rows_view, workspace
 
 TCN_HIDDEN = 512
 TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
@@ -185,7 +185,8 @@ class FSNEngine:
         G = self.G if B > 1 else 1
         Fo = self.F if G <= 1 else (self.F - self.F % G) // G
         d["G"], d["Fo"], d["Nseq"] = G, Fo, B * Fo
-        d["x_tm"] = torch.empty(Tv, B * Fo, self.KX, dtype=dt, device=dev)
+        d["x_rows"] = torch.zeros(padded_rows(Tv * B * Fo, B * Fo), self.KX, dtype=dt, device=dev)   # GEMM operand
+        d["x_tm"] = rows_view(d["x_rows"], Tv, B * Fo)
         if train:
             d["tsse_saved"] = {k: torch.empty(3, self.nm, B, *shp, dtype=torch.float32, device=dev)
                                for k, shp in (("ns", ()), ("pre", (self.F, 3)), ("sq", (self.F,)),
@@ -267,7 +268,7 @@ class FSNEngine:
         H.call("nppc_subband_mean", prec, src, ldS, d["fb"], ldF, R * ldF, self.mult, d["sbscale"], B, F, Tp, Tv,
                self.I, s)
         H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
-               self.nb, self.G, self.KX, s)
+               self.nb, self.G, self.KX, int(train), s)
         # 7: two-layer LSTM over T' steps for the B*F' sequences
         lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile)      # mtile None: cooperative kernel when the shape allows
         d["lstm"] = lo
@@ -308,6 +309,56 @@ class FSNEngine:
         H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, dst, dst_ld, out_rows, col0, ncols, permH, accumulate,
                S * rows * ncolsN, sDst, batch, s)
 
+    def _lstm_wgrad(self, dg1, dg2, x_rows, h1_rows, h2_rows, Tv, Nseq):
+        s = H.stream()
+        dt, dev, Hd, I, KX = self.dt, self.dev, self.Hd, self.I, self.KX
+        K4 = 4 * Hd
+        q = "sb_model.sequence_model."
+        Rr = Tv * Nseq
+        ws = lambda name, shape, dtype=dt, zero=False: workspace(("eng", id(self), name), shape, dtype, dev, zero)
+        jobs = [   # (dgates, row offset of dgates, input rows, input width, destination(s))
+            (dg1, 0, x_rows, KX, ("ih", q + "weight_ih_l0", q + "bias_ih_l0", q + "bias_hh_l0")),
+            (dg2, 0, x_rows, KX, ("bias", None, q + "bias_ih_l1", q + "bias_hh_l1")),
+            (dg2, 0, h1_rows, Hd, ("w", q + "weight_ih_l1")),
+        ]
+        if Tv > 1:
+            jobs += [(dg1, Nseq, h1_rows, Hd, ("w", q + "weight_hh_l0")), (dg2, Nseq, h2_rows, Hd, ("w", q + "weight_hh_l1"))]
+
+        def scatter(slab, S, rows, ncolsN, dest):
+            kind = dest[0]
+            if kind in ("ih", "w"):
+                ncol = I if kind == "ih" else Hd
+                H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, self.g(dest[1]), ncol, K4, 0, ncol, Hd, 0, 0, 0, 1, s)
+            if kind in ("ih", "bias"):
+                H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, self.g(dest[2]), 1, K4, I, 1, Hd, 0, 0, 0, 1, s)
+                self.g(dest[3]).copy_(self.g(dest[2]))
+
+        if self.prec == H.PREC_BF16 and K4 % 128 == 0 and Hd % 64 == 0 and KX % 64 == 0:
+            S = 16
+            slab = ws("slab", (S * K4 * max(Hd, KX),), torch.float32)
+            for dg, off, inp, width, dest in jobs:
+                rows = (Rr - off + 64 * S - 1) // (64 * S) * (64 * S)
+                H.call("nppc_gemm_tn_splitk", dg.view(-1)[off * K4:], K4, inp, width, slab, width, K4, width, rows, S, s)
+                scatter(slab, S, K4, width, dest)
+            return
+        # generic path (fp32 parity mode, small hidden sizes): transposed copies + the NT split-K GEMM
+        bk = 64 if self.prec == H.PREC_BF16 else 32
+        Rp = rup(Rr, bk)
+        K4p, Hp, KXp = rup(K4, 128), rup(Hd, 128), rup(KX, 128)
+        dgT = [ws("dg1T", (K4p, Rp), zero=True), ws("dg2T", (K4p, Rp), zero=True)]
+        for src, dst in ((dg1, dgT[0]), (dg2, dgT[1])):
+            H.call("nppc_transpose", self.prec, src, dst, Rr, K4, K4, Rp, 0, 0, 0, 1, s)
+        slab = ws("slab", (K4p * max(Hp, KXp),), torch.float32)
+        for dg, off, inp, width, dest in jobs:
+            wp = rup(width, 128)
+            name = f"inT_{id(inp)}_{off}"
+            inT = ws(name, (wp, Rp), zero=True)
+            # shifted product: input row r pairs with dgates row r + off -> place it at column r + off (scalar stores)
+            H.call("nppc_transpose", self.prec, inp, inT.view(-1)[off:], Rr - off, width, width, Rp, 0, 0, 0, 1, s)
+            A = dgT[0] if dg is dg1 else dgT[1]
+            H.call("nppc_gemm_nt_splitk", self.prec, A, Rp, inT, Rp, slab, wp, K4p, wp, Rp, 1, s)
+            scatter(slab, 1, K4p, wp, dest)
+
     def backward(self, dout):
         """dout [B', O, F', T] fp32 -> flat parameter gradient (same layout as the flat parameter buffer)."""
         d = self.last
@@ -327,34 +378,11 @@ class FSNEngine:
         H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
                self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
         # ---- 2. LSTM recurrence backward
-        dx, dg1T, dg2T = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
-        # ---- 3. LSTM weight gradients: K-contiguous NT GEMMs on the transposed tensors
-        Np = padded_rows(Nseq)
-        Rp = Tv * Np
-        KXn = rup(self.KX, 128)
-        xT = ws("xT", (KXn, Rp), zero=True)
-        H.call("nppc_transpose", prec, d["x_tm"], xT, Nseq, self.KX, self.KX, Rp, Nseq * self.KX, Np, 0, Tv, s)
-        xT[self.I].fill_(1.0)     # spare padded row = ones: its GEMM column is the bias gradient (sum over rows of dgates)
-        S = 1
-        while S < 16 and (Np // 64) % (2 * S) == 0 and Np % 64 == 0:
-            S *= 2
-        K4 = 4 * Hd
-        K4p, HdN = dg1T.shape[0], lo["h1T"].shape[0]
-        slab = ws("slab", (S * K4p * max(HdN, KXn),), torch.float32)
-        q = "sb_model.sequence_model."
-        I = self.I
-        self._wgrad(dg1T, Rp, 0, xT, Rp, 0, K4p, KXn, Rp, S, q + "weight_ih_l0", I, K4, I, slab, permH=Hd)
-        H.call("nppc_reduce_slabs", slab, S, K4p * KXn, KXn, self.g(q + "bias_ih_l0"), 1, K4, I, 1, Hd, 0, 0, 0, 1, s)
-        self.g(q + "bias_hh_l0").copy_(self.g(q + "bias_ih_l0"))
-        self._wgrad(dg2T, Rp, 0, xT, Rp, 0, K4p, KXn, Rp, S, self.g(q + "bias_ih_l1"), 1, K4, 1, slab, permH=Hd, col0=I)
-        self.g(q + "bias_hh_l1").copy_(self.g(q + "bias_ih_l1"))
-        self._wgrad(dg2T, Rp, 0, lo["h1T"], Rp, 0, K4p, HdN, Rp, S, q + "weight_ih_l1", Hd, K4, Hd, slab, permH=Hd)
-        if Tv > 1:
-            # h_{t-1}: the same transposed tensors, shifted by one time block (column offset Np)
-            self._wgrad(dg1T.view(-1)[Np:], Rp, 0, lo["h1T"], Rp, 0, K4p, HdN, Rp - Np, S, q + "weight_hh_l0", Hd, K4, Hd,
-                        slab, permH=Hd)
-            self._wgrad(dg2T.view(-1)[Np:], Rp, 0, lo["h2T"], Rp, 0, K4p, HdN, Rp - Np, S, q + "weight_hh_l1", Hd, K4, Hd,
-                        slab, permH=Hd)
+        dx, dg1, dg2 = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
+        # ---- 3. LSTM weight gradients: dW[k][c] = sum_rows dgates[row][k] * input[row][c], rows = (t, sequence).
+        # Row-major operands straight from the recurrent kernels; h_{t-1} is the same buffer one time block (Nseq rows)
+        # earlier; the staged input carries a ones column (index I), so its product column is the bias gradient.
+        self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq)
         # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
         dpre_fb = ws("dpre_fb", (3, B, Tp, ldF), zero=True)
         Dsb = ws("Dsb", (B,), torch.float64)

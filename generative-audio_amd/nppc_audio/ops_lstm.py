@@ -52,13 +52,8 @@ def pick_mtile(n_seq, prec, train, n_cu=256):
     return 1
 
 
-def padded_rows(N):
-    """time-block stride of the transposed tensors: multiple of 32 so K-slices stay MFMA aligned"""
-    return (N + 31) // 32 * 32
-
-
 _WS = {}
-COOP = True          # use the cooperative (weights split over CU pairs) forward kernel when the shape allows it
+COOP = True          # use the cooperative (weights split over CU pairs) kernels when the shape allows it
 N_CU = None
 
 
@@ -84,24 +79,41 @@ def workspace(key, shape, dtype, device, zero=False):
     return t
 
 
+ROW_PAD = 1024       # row granularity of the weight-gradient GEMM operands (64 rows x up to 16 K-splits)
+
+
+def padded_rows(R, shift=0):
+    """rows to allocate for a [R][cols] GEMM operand: whole ROW_PAD blocks, plus slack for the one-step shift"""
+    return (R + ROW_PAD - 1) // ROW_PAD * ROW_PAD + ROW_PAD + shift
+
+
+def rows_view(flat, Tn, N):
+    """[Rpad][cols] zero-padded operand buffer -> its live [Tn][N][cols] prefix"""
+    return flat[:Tn * N].view(Tn, N, flat.shape[1])
+
+
 def lstm2_forward(x_tm, packed, train, mtile=None):
-    """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1T, h2T, g1, g2, c1, c2]).
-    Transposed tensors are [rows][Tn*Np] with column t*Np + n (Np = padded_rows(N), padding zero)."""
+    """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1, g1, g2, c1, c2]) time-major.
+    In train mode h1/h2 are prefixes of zero-padded row buffers (`h1_rows`, `h2_rows`: [Rpad][H]) that the
+    weight-gradient GEMMs read directly."""
     Tn, N, kx = x_tm.shape
-    Np = padded_rows(N)
     assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
     dt, dev = x_tm.dtype, x_tm.device
     tag = ("lstm", id(packed), train)
-    out = {"h2": workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)}
+    out = {}
     if train:
-        Hr = (Hd + 127) // 128 * 128       # row padding so the tensors can be GEMM B-operands (N % 128 == 0)
-        out["h1T"] = workspace(tag + ("h1T",), (Hr, Tn * Np), dt, dev, zero=True)
-        out["h2T"] = workspace(tag + ("h2T",), (Hr, Tn * Np), dt, dev, zero=True)
+        Rp = padded_rows(Tn * N, N)
+        out["h1_rows"] = workspace(tag + ("h1",), (Rp, Hd), dt, dev, zero=True)
+        out["h2_rows"] = workspace(tag + ("h2",), (Rp, Hd), dt, dev, zero=True)
+        out["h1"] = rows_view(out["h1_rows"], Tn, N)
+        out["h2"] = rows_view(out["h2_rows"], Tn, N)
         out["c1"] = workspace(tag + ("c1",), (Tn, N, Hd), dt, dev)
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
+    else:
+        out["h2"] = workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)
     if (COOP and mtile is None) or isinstance(mtile, tuple):
         G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if isinstance(mtile, tuple):               # (G, mtile) forced by a test / benchmark
@@ -117,15 +129,15 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
             flags = workspace(tag + ("coop_flags",), (ncl * 2 * G + 4,), torch.int32, dev, zero=True)
             _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
                 "nppc_lstm2_fwd_coop", packed.prec, int(train), G, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
-                packed.bias2, out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"),
-                out.get("c2"), xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, Np, H.stream()))
+                packed.bias2, out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), xch,
+                xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, H.stream()))
             return out
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
     _timed(("lstm2_fwd", int(train), N, Tn, mtile), lambda: H.call(
         "nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
-        out["h2"], out.get("h1T"), out.get("h2T"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn,
-        packed.I, Hd, Np, H.stream()))
+        out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
+        H.stream()))
     return out
 
 
@@ -155,16 +167,15 @@ class PackedLSTMBwd:
 
 
 def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
-    """saved = lstm2_forward(train=True) dict; dh2 [Tn][N][H] -> dx [Tn][N][kx], dg1T, dg2T [4H][Tn*N]
-    (transposed gate gradients, row k = unit*4 + gate in (i,g,f,o) order)."""
+    """saved = lstm2_forward(train=True) dict; dh2 [Tn][N][H] -> (dx [Tn][N][kx], dg1_rows, dg2_rows): the gate gradients
+    as zero-padded row buffers [Rpad][4H] (row t*N + n, column unit*4 + gate in (i,g,f,o) order)."""
     Tn, N, Hd = saved["h2"].shape
     dt, dev = dh2.dtype, dh2.device
-    Np = padded_rows(N)
     tag = ("lstm_bwd", id(packed_bwd))
     dx = workspace(tag + ("dx",), (Tn, N, kx), dt, dev)
-    Kr = (4 * Hd + 127) // 128 * 128   # row padding so the tensors can be GEMM A-operands (R % 128 == 0)
-    dg1T = workspace(tag + ("dg1T",), (Kr, Tn * Np), dt, dev, zero=True)
-    dg2T = workspace(tag + ("dg2T",), (Kr, Tn * Np), dt, dev, zero=True)
+    Rp = padded_rows(Tn * N, N)
+    dg1 = workspace(tag + ("dg1",), (Rp, 4 * Hd), dt, dev, zero=True)
+    dg2 = workspace(tag + ("dg2",), (Rp, 4 * Hd), dt, dev, zero=True)
     use_coop = (COOP if coop is None else coop) and packed_bwd.coop and ((N + 31) // 32) * 2 <= _n_cu()
     if use_coop:
         ncl = (N + 31) // 32
@@ -172,9 +183,9 @@ def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
         flags = workspace(tag + ("coop_flags",), (ncl * 4 + 4,), torch.int32, dev, zero=True)
         _timed(("lstm2_bwd_coop_g2", 1, N, Tn, 2), lambda: H.call(
             "nppc_lstm2_bwd_coop", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.cwb1, packed_bwd.cwb2,
-            dx, dg1T, dg2T, xch, xch.numel() * xch.element_size(), flags, N, Tn, Np, _n_cu(), H.stream()))
-        return dx, dg1T, dg2T
+            dx, dg1, dg2, xch, xch.numel() * xch.element_size(), flags, N, Tn, _n_cu(), H.stream()))
+        return dx, dg1, dg2
     _timed(("lstm2_bwd", 1, N, Tn, 1), lambda: H.call(
         "nppc_lstm2_bwd", packed_bwd.prec, saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.wb1,
-        packed_bwd.wb2, dx, dg1T, dg2T, N, Tn, packed_bwd.I, Hd, Np, H.stream()))
-    return dx, dg1T, dg2T
+        packed_bwd.wb2, dx, dg1, dg2, N, Tn, packed_bwd.I, Hd, H.stream()))
+    return dx, dg1, dg2

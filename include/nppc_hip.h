@@ -97,7 +97,7 @@ int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, floa
 int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* mult,
                       float* scale, int B, int F, int Tp, int Tv, int nfeat, void* stream);
 int nppc_subband_stage(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* scale,
-                       void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, void* stream);
+                       void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, int ones_col, void* stream);
 int nppc_subband_stage_bwd(int prec, const void* dx, const void* x, const void* fb, const float* scale, double* D,
                            void* dpre, int B, int F, int Tp, int Tv, int ldF, long strideFb, int nb, int G, int KX,
                            void* stream);
@@ -112,33 +112,31 @@ int nppc_lstm2_packed_elems(int I, int H, long* n1, long* n2, int* kx);
 int nppc_lstm2_pack_weights(int prec, const float* w_ih0, const float* w_hh0, const float* b_ih0, const float* b_hh0,
                             const float* w_ih1, const float* w_hh1, const float* b_ih1, const float* b_hh1, int I, int H,
                             void* wp1, void* wp2, float* bias1, float* bias2, void* stream);
-/* x [Tn][N][kx]; h2 [Tn][N][H] time-major; when train also c1,c2 [Tn][N][H], g1,g2 [Tn][N][H][4] (i,g,f,o) and the
- * transposed hidden states h1T,h2T [rows >= H][Tn*Np] (column of (t,n) = t*Np + n) for the weight-gradient GEMMs. */
+/* x [Tn][N][kx]; h2 [Tn][N][H] time-major; when train also h1, c1, c2 [Tn][N][H] and g1, g2 [Tn][N][H][4] (i,g,f,o) */
 int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                   const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1, void* c2, long N,
-                   int Tn, int I, int H, long Np, void* stream);
+                   const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2, long N, int Tn, int I,
+                   int H, void* stream);
 /* Cooperative forward: G workgroups (CUs) share a tile of 16*mtile sequences and split the hidden units, each streaming
  * 1/G of the weights; h slices cross CUs through `xch` with bounded-spin epoch flags (`flags`, zeroed by the launcher;
  * the word after the last flag is set on a spin timeout).  Same tensor contract as nppc_lstm2_fwd. */
 int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, int* mtile, int* clusters);
 int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
-                        const float* bias1, const float* bias2, void* h2, void* h1T, void* h2T, void* g1, void* g2, void* c1,
-                        void* c2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, long Np,
-                        void* stream);
+                        const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                        void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, void* stream);
 /* cooperative backward (bf16, H = 384): CU pairs share 32 sequences, each owns half the hidden units / output columns */
 int nppc_lstm2_coop_bwd_packed_elems(long* n);
 int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
                              void* wb2, void* stream);
 int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
-                        const void* wb2, void* dx, void* dg1T, void* dg2T, void* xch, long xch_bytes, unsigned* flags, long N,
-                        int Tn, long Np, int n_cu, void* stream);
+                        const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
+                        int Tn, int n_cu, void* stream);
 int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
 int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
                                 int I, int H, void* wb1, void* wb2, void* stream);
-/* dh2 [Tn][N][H] -> dx [Tn][N][kx], dg1T/dg2T [rows >= 4H][Tn*Np] (row k = unit*4 + gate in i,g,f,o order) */
+/* dh2 [Tn][N][H] -> dx [Tn][N][kx], gate gradients dg1/dg2 [Tn][N][4H] (column k = unit*4 + gate in i,g,f,o order) */
 int nppc_lstm2_bwd(int prec, const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2,
-                   const void* wb1, const void* wb2, void* dx, void* dg1T, void* dg2T, long N, int Tn, int I, int H,
-                   long Np, void* stream);
+                   const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, long N, int Tn, int I, int H,
+                   void* stream);
 
 /* ---- Gram-Schmidt on the K complex directions + NPPC loss ----------------------------------------------------
  * nppc_audio/pc_wrapper.py:8-44 (gram_schmidt_to_crm), nppc_audio/trainer.py:259-317 (base_step) */
