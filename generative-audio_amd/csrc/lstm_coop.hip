@@ -216,11 +216,46 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     }
   };
 
+  // every wave polls for itself and fetches its own share of a partner slice into registers (no workgroup barrier):
+  // used for the h2 hand-off, whose LDS region nobody reads during layer 1, so the transfer hides behind its GEMMs
+  constexpr int HXC = (SLICE_CH * (G - 1) + NT - 1) / NT;
+  auto wave_poll = [&](int layer, int ep) {
+    if (lane < G && lane != cu) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) {
+          __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto slice_addr = [&](int idx, int& partner, int& ch) {      // idx-th chunk over the G-1 partner slices
+    const int pi = idx / SLICE_CH;
+    partner = pi < cu ? pi : pi + 1;
+    ch = idx % SLICE_CH;
+  };
+
 #pragma unroll 1
   for (int t = 0; t < a.Tn; ++t) {
     const int p = t & 1;
     const int ep = t + 1;
     const size_t ebase = ((size_t)t * N + rbase) * H + unit_n;
+    u32x4 hx[HXC];
+    if (t > 0) {
+      wave_poll(1, ep - 1);
+#pragma unroll
+      for (int u = 0; u < HXC; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < SLICE_CH * (G - 1)) {
+          int pr, ch;
+          slice_addr(idx, pr, ch);
+          hx[u] = load_sc1_b128(xr, ((1 * 2 + ((ep - 1) & 1)) * G + pr) * SLICE * (int)sizeof(T) + ch * 16);
+        }
+      }
+    }
     uint4 xrg[XCH];
     const bool more = t + 1 < a.Tn;
     if (more) {
@@ -280,8 +315,19 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         }
     }
     if (PR) coop_prime<T, DEPTH>(pre, NKH, NKH, nk2, wr2, 0, ublk, lane);       // layer 2, pair (i,g), h2 half
-    // the partners' h2_{t-1} (published at the end of the previous step) -> LDS; nobody reads H2 during layer 1
-    if (t > 0) consume(1, OH2, ep - 1);
+    // the partners' h2_{t-1} (fetched at the top of the step) -> LDS; nobody reads H2 during layer 1
+    if (t > 0) {
+#pragma unroll
+      for (int u = 0; u < HXC; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < SLICE_CH * (G - 1)) {
+          int pr, ch;
+          slice_addr(idx, pr, ch);
+          const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
+          *reinterpret_cast<u32x4*>(lds + r * RS + OH2 + pr * HC + cc * VEC) = hx[u];
+        }
+      }
+    }
     __syncthreads();                                              // (1) all waves done reading h1_{t-1} and x_t
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
