@@ -28,7 +28,7 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-def build_trainer(precision, rank, world, batch, length):
+def build_trainer(precision, rank, world, batch, length, n_dirs=K_DIRS):
     from nppc_audio.data import SyntheticNoisySpeech
     from nppc_audio.fullsubnet import FullSubNet_Plus, FullSubNetPlusConfig
     from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
@@ -41,7 +41,7 @@ def build_trainer(precision, rank, world, batch, length):
         nppc_model_configuration=dict(
             pretrained_restoration_model_configuration=rest_cfg, pretrained_restoration_model_path=ck,
             audio_pc_wrapper_configuration=dict(multi_direction_configuration=dict(
-                num_groups_in_drop_band=2, n_directions=K_DIRS, precision=precision)),
+                num_groups_in_drop_band=2, n_directions=n_dirs, precision=precision)),
             stft_configuration=dict(nfft=NFFT, hop_length=HOP, win_length=NFFT), device="cuda"),
         data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
         data_loader_configuration=dict(batch_size=batch * world, num_workers=0, pin_memory=False, shuffle=False),
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--dirs", type=int, default=K_DIRS, help="number of PC directions K (config C5 uses 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -126,7 +127,7 @@ def main():
 
     from nppc_audio import ops_lstm
     length = int(a.seconds * SR)
-    tr, batch = build_trainer(a.precision, rank, world, a.batch, length)
+    tr, batch = build_trainer(a.precision, rank, world, a.batch, length, a.dirs)
     frames = a.batch * (1 + length // HOP)
 
     def sync():
@@ -179,7 +180,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"C2: speech-enhancement NPPC, FullSubNet+ restorer + K={K_DIRS} direction net, "
+        "config": {"workload": f"{'C2' if (a.batch, a.seconds, a.dirs) == (BATCH, SECONDS, K_DIRS) else 'custom'}: speech-enhancement NPPC, FullSubNet+ restorer + K={K_DIRS} direction net, "
                                f"batch={a.batch}x{a.seconds:g}s@16kHz per GPU, STFT {NFFT}/{HOP}, G_rest=1 G_pc=2, "
                                f"full train step (fwd+loss+bwd+Adam{'+RCCL all-reduce' if world > 1 else ''})",
                    "global_batch": a.batch * world, "frames_per_step_per_gpu": frames,
