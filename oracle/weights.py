@@ -94,8 +94,59 @@ def nppc_spec(n_directions, **kw):
     return spec
 
 
+UNET_PLAN = (   # (block, conv-path prefix inside the block, in_ch, out_ch) -- tmp_utils.py:8-99, unet.py:247-260
+    ("inc", "conv.conv", None, 64), ("down1", "mpconv.1.conv", 64, 128), ("down2", "mpconv.1.conv", 128, 256),
+    ("down3", "mpconv.1.conv", 256, 512), ("down4", "mpconv.1.conv", 512, 512), ("up1", "conv.conv", 1024, 256),
+    ("up2", "conv.conv", 512, 128), ("up3", "conv.conv", 256, 64), ("up4", "conv.conv", 128, 64))
+
+
+def unet_spec(in_channels, out_channels):
+    """Ordered {name: shape} of the inpainting U-Net's state_dict (inpainting/networks/unet.py:247-290;
+    double_conv = Sequential[conv3x3, BatchNorm2d, LeakyReLU, conv3x3, BatchNorm2d, LeakyReLU(, Dropout)],
+    tmp_utils.py:8-37).  BatchNorm buffers are part of the wire format."""
+    spec = OrderedDict()
+    for blk, path, cin, cout in UNET_PLAN:
+        cin = in_channels if cin is None else cin
+        for conv_i, bn_i, ci in ((0, 1, cin), (3, 4, cout)):
+            spec[f"{blk}.{path}.{conv_i}.weight"] = (cout, ci, 3, 3)
+            spec[f"{blk}.{path}.{conv_i}.bias"] = (cout,)
+            spec[f"{blk}.{path}.{bn_i}.weight"] = (cout,)
+            spec[f"{blk}.{path}.{bn_i}.bias"] = (cout,)
+            spec[f"{blk}.{path}.{bn_i}.running_mean"] = (cout,)
+            spec[f"{blk}.{path}.{bn_i}.running_var"] = (cout,)
+            spec[f"{blk}.{path}.{bn_i}.num_batches_tracked"] = ()
+    spec["outc.conv.weight"] = (out_channels, 64, 1, 1)
+    spec["outc.conv.bias"] = (out_channels,)
+    return spec
+
+
+def inpainting_spec(n_dirs):
+    """Spec of the inpainting NPPCModel.state_dict() (inpainting/nppc/nppc_model.py:33-117):
+    RestorationWrapper(UNet(1,1)) under `pretrained_restoration_model.net.`, UNet(2,K) under `pc_wrapper.net.`."""
+    spec = OrderedDict()
+    for k, v in unet_spec(1, 1).items():
+        spec["pretrained_restoration_model.net." + k] = v
+    for k, v in unet_spec(2, n_dirs).items():
+        spec["pc_wrapper.net." + k] = v
+    return spec
+
+
+def _is_unet_bn(name):
+    parts = name.split(".")
+    return len(parts) >= 3 and parts[-3] == "conv" and parts[-2] in ("1", "4")
+
+
 def _draw(name, shape, seed):
     rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    if _is_unet_bn(name):
+        last = name.rsplit(".", 1)[-1]
+        if last == "num_batches_tracked":
+            return np.asarray(7, np.int64)
+        if last == "weight":
+            return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        if last == "running_var":
+            return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)      # bias, running_mean
     leaf = name.rsplit(".", 2)
     last = leaf[-1]
     parent = leaf[-2] if len(leaf) > 1 else ""
@@ -153,3 +204,26 @@ def synth_batch(batch, length, first_clip=0):
         noisy[i] = y.astype(np.float32)
         clean[i] = c.astype(np.float32)
     return noisy, clean
+
+
+def synth_inpaint_batch(batch, n_frames, nfft=255, hop=128, gap_frames=(3, 6), first_clip=0):
+    """Synthetic inpainting batch at the API boundary of NPPCAudioInpaintingTrainer.base_step
+    (inpainting/trainer/nppc_trainer.py:338-350): (masked_spec[B,2,F,T], mask_frames[B,T], clean_spec[B,2,F,T]).
+    Restates the dataset's preparation (dataset/audio_dataset_inpainting.py:154-168, 223-251, 296-313):
+    clean clip scaled to -25 dBFS, STFT (hann, centred), a run of zero frames, masked = clean * mask."""
+    import torch
+    length = (n_frames - 1) * hop + nfft - 2 * (nfft // 2)
+    _, clean = synth_batch(batch, length, first_clip)
+    c = torch.from_numpy(clean)
+    rms = c.pow(2).mean(dim=1, keepdim=True).sqrt()
+    c = c * 10 ** ((-25.0 - 20 * torch.log10(rms + 1e-8)) / 20)
+    spec = torch.stft(c, nfft, hop, nfft, window=torch.hann_window(nfft), return_complex=True)
+    clean_spec = torch.stack((spec.real, spec.imag), dim=1).float().numpy()
+    mask = np.ones((batch, n_frames), np.float32)
+    for i in range(batch):
+        rng = np.random.Generator(np.random.PCG64(4321 + first_clip + i))
+        g = int(rng.integers(gap_frames[0], gap_frames[1] + 1))
+        s = int(rng.integers(2, max(3, n_frames - g - 2)))
+        mask[i, s:s + g] = 0.0
+    masked_spec = clean_spec * mask[:, None, None, :]
+    return masked_spec.astype(np.float32), mask, clean_spec
