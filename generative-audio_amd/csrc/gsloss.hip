@@ -223,22 +223,25 @@ __global__ void gs_bwd_solve_kernel(const double* __restrict__ Gall, const doubl
 __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __restrict__ err_norm, float* __restrict__ proj_re,
                                   float* __restrict__ proj_im, float* __restrict__ proj_mag, float* __restrict__ w_norms,
                                   float* __restrict__ reconst, float* __restrict__ sm, double* __restrict__ coefA,
-                                  double* __restrict__ coefE, int B, int K) {
+                                  double* __restrict__ coefE, int B, int K, double eps, int eps_in_norms) {
+  // eps_in_norms = 0: enhancement trainer (trainer.py:269-298): eps only in the divisors, reported norms are plain.
+  // eps_in_norms = 1: inpainting trainer (inpainting/trainer/nppc_trainer.py:352-372): w_norms and err_norm carry the
+  //                   eps themselves (w_norms = (|w| + eps) / (|e| + eps), err_norm = |e| + eps).
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int KV = K + 1;
   const double* G = Gall + (size_t)b * KV * KV * 2;
   const double en = sqrt(G[(K * KV + K) * 2]);
-  const double de = en + 1e-8;
-  err_norm[b] = (float)en;
+  const double de = en + eps;
+  err_norm[b] = (float)(eps_in_norms ? de : en);
   double rec = 1.0;
   for (int i = 0; i < K; ++i) {
     const double wn = sqrt(G[(i * KV + i) * 2]);
-    const double dw = wn + 1e-8;
+    const double dw = wn + eps;
     const double qr = G[(i * KV + K) * 2], qi = G[(i * KV + K) * 2 + 1];   // q = <w_i, e> = sum conj(w_i) e
     const double pr = qr / (dw * de), pi = qi / (dw * de);
     const double pm2 = pr * pr + pi * pi;
-    const double wno = wn / de;
+    const double wno = (eps_in_norms ? dw : wn) / de;
     proj_re[b * K + i] = (float)pr;
     proj_im[b * K + i] = (float)pi;
     proj_mag[b * K + i] = (float)sqrt(pm2);
@@ -249,7 +252,8 @@ __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __rest
     // d(pm2)/dw = 2 conj(q) e / (dw^2 de^2) - 2 |q|^2 / (dw^3 de^2) * w / wn ;  d(wno^2)/dw = 2 wn/de^2 * w / wn
     // store unit-weight pieces; the host-provided upstream weights are applied in loss_bwd_coef_kernel
     coefA[(b * K + i) * 4 + 0] = -2.0 * (qr * qr + qi * qi) / (dw * dw * dw * de * de) / (wn > 0 ? wn : 1.0);  // d pm2 / dw : w part
-    coefA[(b * K + i) * 4 + 1] = 2.0 * dsm * 2.0 / (de * de);                                                  // d sm  / dw : w part (x w)
+    // d sm / dw : w part (x w):  d(wno^2)/dw = 2 wno / de * w / wn
+    coefA[(b * K + i) * 4 + 1] = 2.0 * dsm * 2.0 * wno / (de * (wn > 0 ? wn : 1.0));
     coefE[(b * K + i) * 2 + 0] = 2.0 * qr / (dw * dw * de * de);     // d pm2 / dw : e part = 2 conj(q) e / (..), conj(q) = (qr, -qi)
     coefE[(b * K + i) * 2 + 1] = -2.0 * qi / (dw * dw * de * de);
   }
@@ -351,7 +355,19 @@ int nppc_loss_solve(const double* G, float* err_norm, float* proj_re, float* pro
                     float* reconst, float* sm, double* coefA, double* coefE, int B, int K, void* stream) {
   if (!G || !err_norm || !coefA || !coefE || K + 1 > KMAX) return NPPC_EBADARG;
   hipLaunchKernelGGL(loss_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, err_norm, proj_re,
-                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K);
+                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, 1e-8, 0);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// Same with the inpainting trainer's epsilon conventions (inpainting/trainer/nppc_trainer.py:352-372): real vectors
+// are passed with a zero imaginary plane; eps = 1e-6 sits inside w_norms and err_norm.
+int nppc_loss_solve_eps(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
+                        float* reconst, float* sm, double* coefA, double* coefE, int B, int K, double eps, int eps_in_norms,
+                        void* stream) {
+  if (!G || !err_norm || !coefA || !coefE || K + 1 > KMAX || !(eps >= 0)) return NPPC_EBADARG;
+  hipLaunchKernelGGL(loss_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, err_norm, proj_re,
+                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, eps, eps_in_norms);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -210,7 +210,12 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, no amsgrad)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                            float gscale) {
+                            float gscale, const double* __restrict__ sumsq, float max_norm) {
+  if (sumsq) {   // torch.nn.utils.clip_grad_norm_: coefficient max_norm / (||g|| + 1e-6), clamped to 1
+    const float total = (float)sqrt(sumsq[0]) * gscale;
+    const float coef = max_norm / (total + 1e-6f);
+    gscale *= coef < 1.f ? coef : 1.f;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
     const float pi = p[i];
@@ -323,7 +328,21 @@ int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double 
   const double bc2s = sqrt(1.0 - pow(b2, (double)step));
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)b1, (float)b2,
-                     (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale);
+                     (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale, (const double*)nullptr, 0.f);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// Adam preceded by clip_grad_norm_(max_norm): `sumsq` is a device scalar holding sum(g^2) of the UNSCALED gradient
+// (nppc_sumsq), so the clip needs no host round trip (inpainting/trainer/nppc_trainer.py:149-154).
+int nppc_adam_step_clip(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                        double wd, int step, double gscale, const double* sumsq, double max_norm, void* stream) {
+  if (!p || !g || !m || !v || !sumsq || n <= 0 || step < 1 || !(max_norm > 0)) return NPPC_EBADARG;
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(b2, (double)step));
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)b1, (float)b2,
+                     (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale, sumsq, (float)max_norm);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -1,0 +1,778 @@
+// U-Net of the inpainting sibling.
+// Reference: nppc_audio/inpainting/networks/unet.py:247-313 (UNet, RestorationWrapper), tmp_utils.py:8-99
+// (double_conv = [conv3x3 pad 1, BatchNorm2d, LeakyReLU(0.2)] x 2, down = MaxPool2d(2) + double_conv,
+// up = bilinear x2 (align_corners) + pad + cat([skip, up]) + double_conv, outconv = conv1x1).
+//
+// Layout: every activation is a haloed NHWC matrix  X[(b*(H+2) + y)*(W+2) + x][ld]  (channels contiguous, one
+// zero pixel all round each image, zero guard rows before and after the buffer).  A 3x3 convolution is then nine
+// row-shifted GEMMs accumulated in registers (implicit GEMM, no im2col):
+//   raw[p][co] = bias[co] + sum_tap sum_ci X[p + off(tap)][ci] * W[co][tap][ci],   off = dy*(W+2) + dx
+// computed for every haloed row p and stored for interior pixels only, so halos stay zero for the next layer and
+// for the batch statistics.  The transposed convolution (input gradient) is the same kernel on flipped/transposed
+// packed weights; the weight gradient is nine row-shifted TN GEMMs (tcn.hip) or the exact-f32 kernel below.
+// The concatenations are channel slices of one buffer (producers write with a channel offset).
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+__device__ __forceinline__ bool interior(long p, long P, int H, int W) {
+  if (p >= P) return false;
+  const int Wp = W + 2, Hp = H + 2;
+  const int x = (int)(p % Wp);
+  const int y = (int)((p / Wp) % Hp);
+  return x >= 1 && x <= W && y >= 1 && y <= H;
+}
+
+// ------------------------------------------------------------------------------------------------ convolution
+struct ConvArgs {
+  const void* A; long lda;            // haloed NHWC input, pointer at pixel row 0 (guard rows exist before it)
+  const void* Wp;                     // packed weights [Np][ntap*Cin], K contiguous
+  void* C; long ldc;                  // haloed NHWC output; interior rows, columns < Cout are written
+  const float* bias;                  // [Cout] or null
+  const float* scale;                 // optional folded BatchNorm (eval mode): v = leaky(v * scale[c] + shift[c])
+  const float* shift;
+  float slope;
+  long P;                             // haloed pixel rows B*(H+2)*(W+2)
+  int H, W, Cin, Cout, ntap;          // Cin % 32 == 0
+  int tapoff[9];
+};
+
+// 256 threads = 4 waves stacked over rows; wave tile 32 x 64, block tile 128 rows x 64 output channels.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs g) {
+  typedef typename Frag<T>::type frag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+  const long r0 = (long)blockIdx.x * 128 + wave * 32;
+  const int c0 = blockIdx.y * 64;
+  const int kc = g.Cin / 32, nk = g.ntap * kc;
+  const long ldw = (long)g.ntap * g.Cin;
+  const T* ap = reinterpret_cast<const T*>(g.A) + (r0 + n) * g.lda + 8 * q;
+  const T* bp = reinterpret_cast<const T*>(g.Wp) + (long)(c0 + n) * ldw + 8 * q;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  frag a0[2], b0[4], a1[2], b1[4];
+  int tap = 0, cc = 0;   // position of the NEXT k-step to load
+  auto ld = [&](frag(&a)[2], frag(&b)[4], int kk) {
+    const long aoff = (long)g.tapoff[tap] * g.lda + 32 * cc;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[mi] = load_frag<T>(ap + (long)16 * mi * g.lda + aoff);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b[ni] = load_frag<T>(bp + (long)16 * ni * ldw + 32 * kk);
+    if (++cc == kc) { cc = 0; ++tap; }
+  };
+  auto mm = [&](frag(&a)[2], frag(&b)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mma16(a[mi], b[ni], acc[mi][ni]);
+  };
+  ld(a0, b0, 0);
+  int kk = 0;
+#pragma unroll 1
+  for (; kk + 2 < nk; kk += 2) {
+    ld(a1, b1, kk + 1);
+    mm(a0, b0);
+    ld(a0, b0, kk + 2);
+    mm(a1, b1);
+  }
+  if (kk + 1 < nk) {
+    ld(a1, b1, kk + 1);
+    mm(a0, b0);
+    mm(a1, b1);
+  } else {
+    mm(a0, b0);
+  }
+  // epilogue: element (row r0 + 16 mi + 4 q + j, col c0 + 16 ni + n)
+  T* C = reinterpret_cast<T*>(g.C);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long row = r0 + 16 * mi + 4 * q + j;
+      if (!interior(row, g.P, g.H, g.W)) continue;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = c0 + 16 * ni + n;
+        if (col >= g.Cout) continue;
+        float v = acc[mi][ni][j] + (g.bias ? g.bias[col] : 0.f);
+        if (g.scale) {
+          v = v * g.scale[col] + g.shift[col];
+          v = v > 0.f ? v : g.slope * v;
+        }
+        C[row * g.ldc + col] = from_f32<T>(v);
+      }
+    }
+}
+
+// weight [Cout][Cin][kh][kw] fp32 -> forward pack  Wf[Np][ntap][Cinp]       (Wf[co][t][ci] = w[co][ci][t])
+//                                  -> backward pack Wb[Cinp64][ntap][Coutp]  (Wb[ci][t][co] = w[co][ci][ntap-1-t])
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cout, int Cin,
+                                 int ntap, int Np, int Cinp, int Mb, int Coutp) {
+  const long nf = (long)Np * ntap * Cinp, nb = wb ? (long)Mb * ntap * Coutp : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = (int)(i % Cinp), t = (int)((i / Cinp) % ntap), co = (int)(i / ((long)Cinp * ntap));
+      wf[i] = from_f32<T>((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + t] : 0.f);
+    } else {
+      const long k = i - nf;
+      const int co = (int)(k % Coutp), t = (int)((k / Coutp) % ntap), ci = (int)(k / ((long)Coutp * ntap));
+      wb[k] = from_f32<T>((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + (ntap - 1 - t)] : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// column sums of a haloed matrix (halo rows are zero): st[c] += sum x, st[C + c] += sum x^2   (fp64 atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ X, long ld, long P, int C, int rows_per_block,
+                                                       double* __restrict__ st) {
+  __shared__ double red[2][256][8];
+  const int cg = C / 8, rl = 256 / cg;               // channel groups of 8, row lanes
+  const int g8 = threadIdx.x % cg, r = threadIdx.x / cg;
+  double s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.0;
+  const long p0 = (long)blockIdx.x * rows_per_block;
+  const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+  if (r < rl)
+    for (long p = p0 + r; p < p1; p += rl) {
+      const T* x = X + p * ld + g8 * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double v = (double)to_f32<T>(x[i]);
+        s1[i] += v;
+        s2[i] += v * v;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+  __syncthreads();
+  // thread t < C reduces channel t over the row lanes
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gg = c / 8, i = c % 8;
+    double a = 0.0, b = 0.0;
+    for (int rr = 0; rr < rl; ++rr) { a += red[0][rr * cg + gg][i]; b += red[1][rr * cg + gg][i]; }
+    atomicAdd(st + c, a);
+    atomicAdd(st + C + c, b);
+  }
+}
+
+// train: batch statistics -> (scale, shift, mean, rstd) and the momentum update of the running buffers
+// eval : running statistics -> (scale, shift)
+__global__ void bn_finalize_kernel(const double* __restrict__ st, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ ss, int C, double n,
+                                   float eps, float momentum, int train) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (train) {
+    mean = st[c] / n;
+    var = st[C + c] / n - mean * mean;
+    if (var < 0) var = 0;
+    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mean);
+    rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * var * (n / (n > 1 ? n - 1 : 1)));
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * rstd;
+  ss[c] = (float)sc;
+  ss[C + c] = (float)((double)beta[c] - mean * sc);
+  ss[2 * C + c] = (float)mean;
+  ss[3 * C + c] = (float)rstd;
+}
+
+// y = leaky(scale * x + shift) on interior pixels, 8 channels per thread; y may be a channel slice (ldy, coff)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                     const float* __restrict__ ss, int C, long P, int H, int W, float slope) {
+  const int cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long p = i / cg;
+  const int c8 = (int)(i % cg) * 8;
+  if (!interior(p, P, H, W)) return;
+  const T* x = X + p * ldx + c8;
+  T* y = Y + p * ldy + c8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = to_f32<T>(x[k]) * ss[c8 + k] + ss[C + c8 + k];
+    v = v > 0.f ? v : slope * v;
+    y[k] = from_f32<T>(v);
+  }
+}
+
+// g = (dyA + dyB) * leaky'(y);  S[c] += sum g,  S[C + c] += sum g * xhat      (fp64 atomics), xhat = (x - mean) rstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dyA, long ldA, const T* __restrict__ dyB,
+                                                            long ldB, const T* __restrict__ Y, long ldy,
+                                                            const T* __restrict__ X, long ldx, const float* __restrict__ ss,
+                                                            int C, long P, int H, int W, float slope, int rows_per_block,
+                                                            double* __restrict__ S) {
+  __shared__ float red[2][256][8];
+  const int cg = C / 8, rl = 256 / cg;
+  const int g8 = threadIdx.x % cg, r = threadIdx.x / cg;
+  float s1[8], s2[8], mean[8], rstd[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s1[i] = s2[i] = 0.f;
+    mean[i] = ss[2 * C + g8 * 8 + i];
+    rstd[i] = ss[3 * C + g8 * 8 + i];
+  }
+  const long p0 = (long)blockIdx.x * rows_per_block;
+  const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+  if (r < rl)
+    for (long p = p0 + r; p < p1; p += rl) {
+      if (!interior(p, P, H, W)) continue;
+      const T* a = dyA + p * ldA + g8 * 8;
+      const T* b = dyB ? dyB + p * ldB + g8 * 8 : nullptr;
+      const T* y = Y + p * ldy + g8 * 8;
+      const T* x = X + p * ldx + g8 * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float gq = to_f32<T>(a[i]) + (b ? to_f32<T>(b[i]) : 0.f);
+        if (!(to_f32<T>(y[i]) > 0.f)) gq *= slope;
+        s1[i] += gq;
+        s2[i] += gq * ((to_f32<T>(x[i]) - mean[i]) * rstd[i]);
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gg = c / 8, i = c % 8;
+    double a = 0.0, b = 0.0;
+    for (int rr = 0; rr < rl; ++rr) { a += (double)red[0][rr * cg + gg][i]; b += (double)red[1][rr * cg + gg][i]; }
+    atomicAdd(S + c, a);
+    atomicAdd(S + C + c, b);
+  }
+}
+
+// dx = scale * (g - S1/n - xhat * S2/n) on interior pixels;  block 0 also writes dgamma = S2, dbeta = S1
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dyA, long ldA, const T* __restrict__ dyB,
+                                                           long ldB, const T* __restrict__ Y, long ldy,
+                                                           const T* __restrict__ X, long ldx, const float* __restrict__ ss,
+                                                           const double* __restrict__ S, T* __restrict__ dX, long lddx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int C, long P,
+                                                           int H, int W, float slope, double n) {
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma[c] = (float)S[C + c];
+      dbeta[c] = (float)S[c];
+    }
+  const int cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long p = i / cg;
+  const int c8 = (int)(i % cg) * 8;
+  if (!interior(p, P, H, W)) return;
+  const T* a = dyA + p * ldA + c8;
+  const T* b = dyB ? dyB + p * ldB + c8 : nullptr;
+  const T* y = Y + p * ldy + c8;
+  const T* x = X + p * ldx + c8;
+  T* d = dX + p * lddx + c8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c8 + k;
+    float gq = to_f32<T>(a[k]) + (b ? to_f32<T>(b[k]) : 0.f);
+    if (!(to_f32<T>(y[k]) > 0.f)) gq *= slope;
+    const float xh = (to_f32<T>(x[k]) - ss[2 * C + c]) * ss[3 * C + c];
+    const float m1 = (float)(S[c] / n), m2 = (float)(S[C + c] / n);
+    d[k] = from_f32<T>(ss[c] * (gq - m1 - xh * m2));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// MaxPool2d(2) (floor mode): first maximum in window scan order wins (strict >), index kept for the backward
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                      unsigned char* __restrict__ idx, int C, int B, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(i % cg) * 8;
+  long o = i / cg;
+  if (o >= (long)B * Ho * Wo) return;
+  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  const long pin = ((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1;
+  const long pout = ((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1;
+  const long offs[4] = {0, 1, (long)(W + 2), (long)(W + 3)};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float best = to_f32<T>(X[pin * ldx + c8 + k]);
+    int bi = 0;
+#pragma unroll
+    for (int t = 1; t < 4; ++t) {
+      const float v = to_f32<T>(X[(pin + offs[t]) * ldx + c8 + k]);
+      if (v > best) { best = v; bi = t; }
+    }
+    Y[pout * ldy + c8 + k] = from_f32<T>(best);
+    idx[pout * C + c8 + k] = (unsigned char)bi;
+  }
+}
+
+// dX[window] = dY routed to the recorded position, zero at the other three (rows/columns outside any window stay 0)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dY, long ldy, const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dX, long ldx, int C, int B, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2, cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(i % cg) * 8;
+  long o = i / cg;
+  if (o >= (long)B * Ho * Wo) return;
+  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  const long pin = ((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1;
+  const long pout = ((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1;
+  const long offs[4] = {0, 1, (long)(W + 2), (long)(W + 3)};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const T gq = dY[pout * ldy + c8 + k];
+    const int bi = idx[pout * C + c8 + k];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dX[(pin + offs[t]) * ldx + c8 + k] = t == bi ? gq : from_f32<T>(0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ upsampling
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): src = dst * (in-1)/(out-1) in fp32,
+// i0 = (int)src, lambda1 = src - i0.  The 2H x 2W result is placed at offset (py, px) inside the (Ht, Wt) target
+// (F.pad to the skip's size, tmp_utils.py:79-84) and written into the channel slice [coff, coff+C) of the target.
+__device__ __forceinline__ void bil(int o, int nin, int nout, int& i0, int& i1, float& l0, float& l1) {
+  const float sc = nout > 1 ? (float)(nin - 1) / (float)(nout - 1) : 0.f;
+  const float src = sc * (float)o;
+  i0 = (int)src;
+  i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy, int C,
+                                                       int B, int Hi, int Wi, int Ht, int Wt, int py, int px) {
+  const int Ho = 2 * Hi, Wo = 2 * Wi, cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(i % cg) * 8;
+  long o = i / cg;
+  if (o >= (long)B * Ho * Wo) return;
+  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  bil(yo, Hi, Ho, y0, y1, ly0, ly1);
+  bil(xo, Wi, Wo, x0, x1, lx0, lx1);
+  const long rb = (long)b * (Hi + 2);
+  const long p00 = ((rb + y0 + 1) * (Wi + 2) + x0 + 1) * ldx, p01 = ((rb + y0 + 1) * (Wi + 2) + x1 + 1) * ldx;
+  const long p10 = ((rb + y1 + 1) * (Wi + 2) + x0 + 1) * ldx, p11 = ((rb + y1 + 1) * (Wi + 2) + x1 + 1) * ldx;
+  const long po = (((long)b * (Ht + 2) + yo + py + 1) * (Wt + 2) + xo + px + 1) * ldy;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = ly0 * (lx0 * to_f32<T>(X[p00 + c8 + k]) + lx1 * to_f32<T>(X[p01 + c8 + k])) +
+                    ly1 * (lx0 * to_f32<T>(X[p10 + c8 + k]) + lx1 * to_f32<T>(X[p11 + c8 + k]));
+    Y[po + c8 + k] = from_f32<T>(v);
+  }
+}
+
+// adjoint, as a gather: input pixel (yi, xi) collects every output pixel whose two taps touch it
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dY, long ldy, T* __restrict__ dX, long ldx,
+                                                           int C, int B, int Hi, int Wi, int Ht, int Wt, int py, int px) {
+  const int Ho = 2 * Hi, Wo = 2 * Wi, cg = C / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = (int)(i % cg) * 8;
+  long o = i / cg;
+  if (o >= (long)B * Hi * Wi) return;
+  const int xi = (int)(o % Wi), yi = (int)((o / Wi) % Hi), b = (int)(o / ((long)Wi * Hi));
+  float wy[6], wx[6];
+  int oy[6], ox[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    int a0, a1;
+    float l0, l1;
+    oy[t] = 2 * yi - 2 + t;
+    wy[t] = 0.f;
+    if (oy[t] >= 0 && oy[t] < Ho) {
+      bil(oy[t], Hi, Ho, a0, a1, l0, l1);
+      wy[t] = (a0 == yi ? l0 : 0.f) + (a1 == yi ? l1 : 0.f);
+    }
+    ox[t] = 2 * xi - 2 + t;
+    wx[t] = 0.f;
+    if (ox[t] >= 0 && ox[t] < Wo) {
+      bil(ox[t], Wi, Wo, a0, a1, l0, l1);
+      wx[t] = (a0 == xi ? l0 : 0.f) + (a1 == xi ? l1 : 0.f);
+    }
+  }
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int ty = 0; ty < 6; ++ty) {
+    if (wy[ty] == 0.f) continue;
+    for (int tx = 0; tx < 6; ++tx) {
+      if (wx[tx] == 0.f) continue;
+      const float w = wy[ty] * wx[tx];
+      const T* g = dY + (((long)b * (Ht + 2) + oy[ty] + py + 1) * (Wt + 2) + ox[tx] + px + 1) * ldy + c8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += w * to_f32<T>(g[k]);
+    }
+  }
+  T* d = dX + (((long)b * (Hi + 2) + yi + 1) * (Wi + 2) + xi + 1) * ldx + c8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = from_f32<T>(acc[k]);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// exact-f32 / generic fallback:  slab[z][m][n] = sum_{p in slice z} A[p][m] * Bm[p + shift][n]   (64 x 64 tile per block)
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_simple_kernel(const T* __restrict__ A, long lda, const T* __restrict__ Bm, long ldb,
+                                                           long shift, float* __restrict__ slab, long ldc, long slab_stride,
+                                                           long P, long rows_per_slice) {
+  __shared__ float sa[16][64], sb[16][64];
+  const int tm = threadIdx.x / 16, tn = threadIdx.x % 16;          // 4 x 4 outputs per thread
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const long p0 = (long)blockIdx.z * rows_per_slice;
+  const long p1 = p0 + rows_per_slice < P ? p0 + rows_per_slice : P;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int lr = threadIdx.x / 16, lc = (threadIdx.x % 16) * 4;
+  for (long p = p0; p < p1; p += 16) {
+    const long pr = p + lr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sa[lr][lc + k] = pr < p1 ? to_f32<T>(A[pr * lda + m0 + lc + k]) : 0.f;
+      sb[lr][lc + k] = pr < p1 ? to_f32<T>(Bm[(pr + shift) * ldb + n0 + lc + k]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { av[k] = sa[r][tm * 4 + k]; bv[k] = sb[r][tn * 4 + k]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* out = slab + (size_t)blockIdx.z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[(long)(m0 + tm * 4 + i) * ldc + n0 + tn * 4 + j] = acc[i][j];
+}
+
+// dW[co][ci][t] = sum_s slabs[t][s][co][ci]     (torch layout [Cout][Cin][kh][kw])
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, long slab_stride, long ldc, float* __restrict__ dW,
+                                    int Cout, int Cin, int ntap) {
+  const long total = (long)Cout * Cin * ntap;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), t = (int)(i / ((long)Cin * Cout));
+    const float* s = slabs + (size_t)t * S * slab_stride + (long)co * ldc + ci;
+    double a = 0.0;
+    for (int k = 0; k < S; ++k) a += (double)s[(size_t)k * slab_stride];
+    dW[((long)co * Cin + ci) * ntap + t] = (float)a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ boundary maps
+// log-magnitude of a [B,2,F,T] STFT pair + fp64 sum / sum of squares (utils.py:273-306)
+__global__ __launch_bounds__(256) void logmag_kernel(const float* __restrict__ spec, float* __restrict__ out, long FT, long total,
+                                                     long obs, double* __restrict__ st) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / FT, r = i % FT;
+    const float re = spec[(b * 2) * FT + r], im = spec[(b * 2 + 1) * FT + r];
+    const float v = logf(sqrtf(re * re + im * im) + 1e-6f);
+    out[b * obs + r] = v;
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0 && st) {
+    atomicAdd(st, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(st + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// x <- (x - mean) / std with the batch-global mean and UNBIASED std from st = (sum, sumsq) over n values
+__global__ void standardize_kernel(float* __restrict__ a, float* __restrict__ b, long total, long FT, long bs,
+                                   const double* __restrict__ st, double n, float* __restrict__ mean_std) {
+  const double mean = st[0] / n;
+  double var = (st[1] - n * mean * mean) / (n - 1.0);
+  if (var < 0) var = 0;
+  const float m = (float)mean, s = (float)sqrt(var);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && mean_std) { mean_std[0] = m; mean_std[1] = s; }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long j = (i / FT) * bs + i % FT;
+    a[j] = (a[j] - m) / s;
+    if (b) b[j] = (b[j] - m) / s;
+  }
+}
+
+// NCHW fp32 maps [B][F][T] -> channel c of the haloed NHWC input
+template <typename T>
+__global__ void stage_map_kernel(const float* __restrict__ src, long sbs, T* __restrict__ dst, long ld, int c, int B, int H,
+                                 int W) {
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+    dst[(((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * ld + c] = from_f32<T>(src[(long)b * sbs + (long)y * W + x]);
+  }
+}
+
+// mode 0: out[b][k] = raw[p][k] * (1 - mask[b][t])                           (pc_wrapper.py:78-83)
+// mode 1: out[b][0] = x_in * mask + raw[p][0] * (1 - mask)                    (unet.py:305-312, single channel)
+template <typename T>
+__global__ void unet_out_kernel(const T* __restrict__ raw, long ld, const float* __restrict__ mask, const float* __restrict__ xin,
+                                long xbs, float* __restrict__ out, long ps, int K, int B, int H, int W, int mode) {
+  const long total = (long)B * K * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), k = (int)((i / ((long)W * H)) % K), b = (int)(i / ((long)W * H * K));
+    const float m = mask[(long)b * W + x];
+    const float r = to_f32<T>(raw[(((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * ld + k]);
+    out[((long)b * K + k) * ps + (long)y * W + x] = mode ? xin[(long)b * xbs + (long)y * W + x] * m + r * (1.f - m) : r * (1.f - m);
+  }
+}
+
+// dRaw[p][k] = dOut[b][k][y][x] * (1 - mask[b][x]),  columns K..ld-1 zero
+template <typename T>
+__global__ void unet_out_bwd_kernel(const float* __restrict__ dout, long ps, const float* __restrict__ mask, T* __restrict__ draw,
+                                    long ld, int K, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+    const float m = 1.f - mask[(long)b * W + x];
+    T* d = draw + (((long)b * (H + 2) + y + 1) * (W + 2) + x + 1) * ld;
+    for (int k = 0; k < K; ++k) d[k] = from_f32<T>(dout[((long)b * K + k) * ps + (long)y * W + x] * m);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+static inline int grid_for(long total, int cap = 4096) {
+  long g = (total + 255) / 256;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+// typed launch: KERNEL<bf16_t> or KERNEL<float> with the void* operands cast by the ARGS expression (uses `TT`)
+#define LAUNCH_T(prec, KERNEL, GRID, ...)                                                        \
+  do {                                                                                            \
+    if ((prec) == NPPC_PREC_BF16) {                                                               \
+      typedef bf16_t TT;                                                                          \
+      hipLaunchKernelGGL(KERNEL<TT>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+    } else if ((prec) == NPPC_PREC_F32) {                                                         \
+      typedef float TT;                                                                           \
+      hipLaunchKernelGGL(KERNEL<TT>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);       \
+    } else {                                                                                      \
+      return NPPC_EBADARG;                                                                        \
+    }                                                                                             \
+    NPPC_CHECK_LAUNCH();                                                                          \
+  } while (0)
+
+extern "C" {
+
+int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
+                  const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream) {
+  if (!A || !Wp || !C || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
+  if (Cin % 32 || Np % 64 || Cout > Np || (ksize != 1 && ksize != 3) || (scale && !shift)) return NPPC_EUNSUPPORTED;
+  ConvArgs g;
+  g.A = A; g.lda = lda; g.Wp = Wp; g.C = C; g.ldc = ldc; g.bias = bias; g.scale = scale; g.shift = shift; g.slope = slope;
+  g.P = (long)B * (H + 2) * (W + 2);
+  g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ntap = ksize * ksize;
+  for (int t = 0; t < 9; ++t) g.tapoff[t] = 0;
+  if (ksize == 3)
+    for (int t = 0; t < 9; ++t) g.tapoff[t] = (t / 3 - 1) * (W + 2) + (t % 3 - 1);
+  dim3 grid(ceil_div(g.P, 128), Np / 64);
+  LAUNCH_T(prec, conv_kernel, grid, g);
+  return NPPC_OK;
+}
+
+int nppc_conv_pack(int prec, const float* w, void* wf, void* wb, int Cout, int Cin, int ksize, int Np, int Cinp, int Mb,
+                   int Coutp, void* stream) {
+  if (!w || !wf || Cout > Np || Cin > Cinp || (wb && (Cin > Mb || Cout > Coutp))) return NPPC_EBADARG;
+  const int ntap = ksize * ksize;
+  const long total = (long)Np * ntap * Cinp + (wb ? (long)Mb * ntap * Coutp : 0);
+  LAUNCH_T(prec, conv_pack_kernel, dim3(grid_for(total)), w, (TT*)wf, (TT*)wb, Cout, Cin, ntap, Np, Cinp, Mb, Coutp);
+  return NPPC_OK;
+}
+
+int nppc_bn_stats(int prec, const void* X, long ld, long P, int C, double* st, void* stream) {
+  if (!X || !st || C <= 0 || C % 8 || C / 8 > 256) return NPPC_EBADARG;
+  const int rpb = 1024;
+  LAUNCH_T(prec, bn_stats_kernel, dim3(ceil_div(P, rpb)), (const TT*)X, ld, P, C, rpb, st);
+  return NPPC_OK;
+}
+
+int nppc_bn_finalize(const double* st, const float* gamma, const float* beta, float* rmean, float* rvar, float* ss, int C,
+                     double n, float eps, float momentum, int train, void* stream) {
+  if (!gamma || !beta || !rmean || !rvar || !ss || (train && !st) || C <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, st, gamma, beta, rmean, rvar,
+                     ss, C, n, eps, momentum, train);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_bn_act(int prec, const void* X, long ldx, void* Y, long ldy, const float* ss, int C, int B, int H, int W, float slope,
+                void* stream) {
+  if (!X || !Y || !ss || C % 8) return NPPC_EBADARG;
+  const long P = (long)B * (H + 2) * (W + 2);
+  LAUNCH_T(prec, bn_act_kernel, dim3(ceil_div(P * (C / 8), 256)), (const TT*)X, ldx, (TT*)Y, ldy, ss, C, P, H, W, slope);
+  return NPPC_OK;
+}
+
+int nppc_bn_bwd(int prec, const void* dyA, long ldA, const void* dyB, long ldB, const void* Y, long ldy, const void* X, long ldx,
+                const float* ss, double* S, void* dX, long lddx, float* dgamma, float* dbeta, int C, int B, int H, int W,
+                float slope, void* stream) {
+  if (!dyA || !Y || !X || !ss || !S || !dX || !dgamma || !dbeta || C % 8 || C / 8 > 256) return NPPC_EBADARG;
+  const long P = (long)B * (H + 2) * (W + 2);
+  const int rpb = 1024;
+  const double n = (double)B * H * W;
+  if (hipMemsetAsync(S, 0, sizeof(double) * 2 * C, (hipStream_t)stream) != hipSuccess) return NPPC_ELAUNCH;
+  LAUNCH_T(prec, bn_bwd_reduce_kernel, dim3(ceil_div(P, rpb)), (const TT*)dyA, ldA, (const TT*)dyB, ldB, (const TT*)Y, ldy,
+           (const TT*)X, ldx, ss, C, P, H, W, slope, rpb, S);
+  LAUNCH_T(prec, bn_bwd_apply_kernel, dim3(ceil_div(P * (C / 8), 256)), (const TT*)dyA, ldA, (const TT*)dyB, ldB, (const TT*)Y,
+           ldy, (const TT*)X, ldx, ss, (const double*)S, (TT*)dX, lddx, dgamma, dbeta, C, P, H, W, slope, n);
+  return NPPC_OK;
+}
+
+int nppc_maxpool2(int prec, const void* X, long ldx, void* Y, long ldy, unsigned char* idx, int C, int B, int H, int W,
+                  void* stream) {
+  if (!X || !Y || !idx || C % 8 || H < 2 || W < 2) return NPPC_EBADARG;
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  LAUNCH_T(prec, maxpool_kernel, dim3(ceil_div(total, 256)), (const TT*)X, ldx, (TT*)Y, ldy, idx, C, B, H, W);
+  return NPPC_OK;
+}
+
+int nppc_maxpool2_bwd(int prec, const void* dY, long ldy, const unsigned char* idx, void* dX, long ldx, int C, int B, int H, int W,
+                      void* stream) {
+  if (!dY || !dX || !idx || C % 8 || H < 2 || W < 2) return NPPC_EBADARG;
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  LAUNCH_T(prec, maxpool_bwd_kernel, dim3(ceil_div(total, 256)), (const TT*)dY, ldy, idx, (TT*)dX, ldx, C, B, H, W);
+  return NPPC_OK;
+}
+
+int nppc_upsample2(int prec, const void* X, long ldx, void* Y, long ldy, int C, int B, int Hi, int Wi, int Ht, int Wt,
+                   void* stream) {
+  if (!X || !Y || C % 8 || Ht < 2 * Hi || Wt < 2 * Wi) return NPPC_EBADARG;
+  const int py = (Ht - 2 * Hi) / 2, px = (Wt - 2 * Wi) / 2;
+  const long total = (long)B * 4 * Hi * Wi * (C / 8);
+  LAUNCH_T(prec, upsample_kernel, dim3(ceil_div(total, 256)), (const TT*)X, ldx, (TT*)Y, ldy, C, B, Hi, Wi, Ht, Wt, py, px);
+  return NPPC_OK;
+}
+
+int nppc_upsample2_bwd(int prec, const void* dY, long ldy, void* dX, long ldx, int C, int B, int Hi, int Wi, int Ht, int Wt,
+                       void* stream) {
+  if (!dY || !dX || C % 8 || Ht < 2 * Hi || Wt < 2 * Wi) return NPPC_EBADARG;
+  const int py = (Ht - 2 * Hi) / 2, px = (Wt - 2 * Wi) / 2;
+  const long total = (long)B * Hi * Wi * (C / 8);
+  LAUNCH_T(prec, upsample_bwd_kernel, dim3(ceil_div(total, 256)), (const TT*)dY, ldy, (TT*)dX, ldx, C, B, Hi, Wi, Ht, Wt, py, px);
+  return NPPC_OK;
+}
+
+// Weight gradient of a ksize x ksize convolution:  slabs[t][s][m][n] = sum_{p in slice s} dY[p][m] * X[p + off(t)][n].
+// bf16 with M % 128 == 0 (or M == 64: computed as 128 with the upper half discarded), N % 64 == 0 runs on the MFMA
+// TN GEMM; everything else on the exact-f32 tile kernel.  Rows beyond P must be readable and dY zero there.
+int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* slabs, int M, int N, int B, int H, int W,
+                    int ksize, int ksplit, void* stream) {
+  if (!dY || !X || !slabs || M % 64 || N % 64 || ksplit < 1 || (ksize != 1 && ksize != 3)) return NPPC_EBADARG;
+  const long P = (long)B * (H + 2) * (W + 2);
+  const int ntap = ksize * ksize;
+  const int Mr = (M + 127) / 128 * 128;
+  const long slab_stride = (long)Mr * N;
+  for (int t = 0; t < ntap; ++t) {
+    const long off = ksize == 3 ? (long)(t / 3 - 1) * (W + 2) + (t % 3 - 1) : 0;
+    float* out = slabs + (size_t)t * ksplit * slab_stride;
+    if (prec == NPPC_PREC_BF16) {
+      const long R = (P + 64L * ksplit - 1) / (64L * ksplit) * (64L * ksplit);
+      const int rc = nppc_gemm_tn_splitk(dY, lddy, (const bf16_t*)X + off * ldx, ldx, out, N, Mr, N, R, ksplit, stream);
+      if (rc != NPPC_OK) return rc;
+    } else if (prec == NPPC_PREC_F32) {
+      const long rps = ((P + ksplit - 1) / ksplit + 15) / 16 * 16;
+      hipLaunchKernelGGL(wgrad_simple_kernel<float>, dim3(M / 64, N / 64, ksplit), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)dY, lddy, (const float*)X, ldx, off, out, (long)N, slab_stride, P, rps);
+      NPPC_CHECK_LAUNCH();
+    } else {
+      return NPPC_EBADARG;
+    }
+  }
+  return NPPC_OK;
+}
+
+int nppc_conv_wgrad_reduce(const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize, void* stream) {
+  if (!slabs || !dW || Cout > M || Cin > N) return NPPC_EBADARG;
+  const int Mr = (M + 127) / 128 * 128;
+  const long total = (long)Cout * Cin * ksize * ksize;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, (long)Mr * N,
+                     (long)N, dW, Cout, Cin, ksize * ksize);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_logmag(const float* spec, float* out, long out_bstride, int B, long FT, double* st, void* stream) {
+  if (!spec || !out || B <= 0 || FT <= 0 || out_bstride < FT) return NPPC_EBADARG;
+  const long total = (long)B * FT;
+  hipLaunchKernelGGL(logmag_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, spec, out, FT, total,
+                     out_bstride, st);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_standardize(float* a, float* b_or_null, long bstride, int B, long FT, const double* st, float* mean_std, void* stream) {
+  const long total = (long)B * FT;
+  if (!a || !st || total < 2 || bstride < FT) return NPPC_EBADARG;
+  hipLaunchKernelGGL(standardize_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, a, b_or_null, total, FT,
+                     bstride, st, (double)total, mean_std);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_unet_stage_map(int prec, const float* src, long src_bstride, void* dst, long ld, int c, int B, int H, int W,
+                        void* stream) {
+  if (!src || !dst || c < 0 || c >= ld || src_bstride < (long)H * W) return NPPC_EBADARG;
+  LAUNCH_T(prec, stage_map_kernel, dim3(grid_for((long)B * H * W)), src, src_bstride, (TT*)dst, ld, c, B, H, W);
+  return NPPC_OK;
+}
+
+int nppc_unet_out(int prec, const void* raw, long ld, const float* mask, const float* xin, long xin_bstride, float* out,
+                  long out_pstride, int K, int B, int H, int W, int mode, void* stream) {
+  if (!raw || !mask || !out || (mode && (!xin || K != 1)) || out_pstride < (long)H * W) return NPPC_EBADARG;
+  LAUNCH_T(prec, unet_out_kernel, dim3(grid_for((long)B * K * H * W)), (const TT*)raw, ld, mask, xin, xin_bstride, out,
+           out_pstride, K, B, H, W, mode);
+  return NPPC_OK;
+}
+
+int nppc_unet_out_bwd(int prec, const float* dout, long dout_pstride, const float* mask, void* draw, long ld, int K, int B,
+                      int H, int W, void* stream) {
+  if (!dout || !mask || !draw || K > ld || dout_pstride < (long)H * W) return NPPC_EBADARG;
+  LAUNCH_T(prec, unet_out_bwd_kernel, dim3(grid_for((long)B * H * W)), dout, dout_pstride, mask, (TT*)draw, ld, K, B, H, W);
+  return NPPC_OK;
+}
+
+int nppc_sumsq(const float* g, long n, double* out, void* stream) {
+  if (!g || !out || n <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

@@ -107,6 +107,26 @@ SIGS = {
     "nppc_subband_stage_bwd": [I, P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, P],
     "nppc_reduce_slabs": [P, I, L, L, P, L, I, I, I, I, I, L, L, I, P],
     "nppc_adam_step": [P, P, P, P, L, D, D, D, D, D, I, D, P],
+    "nppc_loss_solve_eps": [P, P, P, P, P, P, P, P, P, P, I, I, D, I, P],
+    "nppc_sumsq": [P, L, P, P],
+    "nppc_adam_step_clip": [P, P, P, P, L, D, D, D, D, D, I, D, P, D, P],
+    "nppc_logmag": [P, P, L, I, L, P, P],
+    "nppc_standardize": [P, P, L, I, L, P, P, P],
+    "nppc_unet_stage_map": [I, P, L, P, L, I, I, I, I, P],
+    "nppc_conv_pack": [I, P, P, P, I, I, I, I, I, I, I, P],
+    "nppc_conv_fwd": [I, P, L, P, P, L, P, P, P, F, I, I, I, I, I, I, I, P],
+    "nppc_conv_wgrad": [I, P, L, P, L, P, I, I, I, I, I, I, I, P],
+    "nppc_conv_wgrad_reduce": [P, I, I, I, P, I, I, I, P],
+    "nppc_bn_stats": [I, P, L, L, I, P, P],
+    "nppc_bn_finalize": [P, P, P, P, P, P, I, D, F, F, I, P],
+    "nppc_bn_act": [I, P, L, P, L, P, I, I, I, I, F, P],
+    "nppc_bn_bwd": [I, P, L, P, L, P, L, P, L, P, P, P, L, P, P, I, I, I, I, F, P],
+    "nppc_maxpool2": [I, P, L, P, L, P, I, I, I, I, P],
+    "nppc_maxpool2_bwd": [I, P, L, P, P, L, I, I, I, I, P],
+    "nppc_upsample2": [I, P, L, P, L, I, I, I, I, I, I, P],
+    "nppc_upsample2_bwd": [I, P, L, P, L, I, I, I, I, I, I, P],
+    "nppc_unet_out": [I, P, L, P, P, L, P, L, I, I, I, I, I, P],
+    "nppc_unet_out_bwd": [I, P, L, P, P, L, I, I, I, I, P],
     "nppc_tcn_gn_bwd": [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_dwconv_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tsse_bwd": [I, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,

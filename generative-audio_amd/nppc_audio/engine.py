@@ -53,6 +53,11 @@ class FlatParams:
         o, shp = self.off[name]
         return self.grad[o:o + int(np.prod(shp))].view(shp)
 
+    def version(self):
+        """changes whenever any parameter was written: in-place torch ops (load_state_dict, torch optimizers) bump the
+        parameter's own counter, the HIP optimizers bump the flat buffer's (trainer.HipAdam / FlatAdamStepper)"""
+        return (self.flat._version, sum(p._version for _, p in self.named))
+
     def ensure_grad(self):
         if self.grad is None:
             self.grad = torch.zeros_like(self.flat)
@@ -126,7 +131,7 @@ class FSNEngine:
         return self.fp.view(name)
 
     def pack_weights(self, force=False):
-        ver = self.fp.flat._version
+        ver = self.fp.version()
         if not force and self.packed_version == ver:
             return
         s = H.stream()
@@ -159,7 +164,7 @@ class FSNEngine:
         q = "sb_model.sequence_model."
         self.lstm.pack(*[self.p(q + n) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0",
                                                   "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
-        self.packed_version = self.fp.flat._version
+        self.packed_version = ver
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B, T, train):

@@ -1,0 +1,87 @@
+"""Inpainting NPPC model: mirrors nppc_audio/inpainting/nppc/nppc_model.py:24-159 (local-checkpoint path;
+the wandb artifact download, :52-98, needs the network and is out of scope -- pass
+`pretrained_restoration_model_path`)."""
+from pathlib import Path
+from typing import Literal, Optional
+
+import pydantic
+import torch
+import torch.nn as nn
+
+from ..networks.unet import RestorationWrapper, UNet, UNetConfig
+from .pc_wrapper import AudioInpaintingPCWrapper, AudioInpaintingPCWrapperConfig
+
+
+class WandbConfig(pydantic.BaseModel):
+    entity: str = "kfirc-tel-aviv-university"
+    project: str = "generative-audio"
+    artifact_name: str
+    artifact_version: str = "latest"
+    checkpoint_filename: str = "checkpoint_final.pt"
+
+
+class NPPCModelConfig(pydantic.BaseModel):
+    pretrained_restoration_model_configuration: UNetConfig
+    pretrained_restoration_model_path: Optional[str] = None
+    wandb_config: Optional[WandbConfig] = None
+    audio_pc_wrapper_configuration: AudioInpaintingPCWrapperConfig
+    device: Literal['cpu', 'cuda'] = 'cuda'
+
+
+class NPPCModel(nn.Module):
+    def __init__(self, config: NPPCModelConfig):
+        super().__init__()
+        self.config = config
+        self.device = config.device
+        if config.device == 'cuda':
+            self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if config.wandb_config:
+            raise NotImplementedError("loading the restorer from a wandb artifact needs the network; "
+                                      "download it and pass pretrained_restoration_model_path")
+        elif config.pretrained_restoration_model_path:
+            self._load_from_local()
+        else:
+            raise ValueError("Either wandb_config or pretrained_restoration_model_path must be provided")
+        self.pc_wrapper = AudioInpaintingPCWrapper(self.config.audio_pc_wrapper_configuration)
+        self.pc_wrapper.to(self.device)
+        self._memo = None
+
+    def _load_from_local(self):
+        """nppc_model.py:100-117: {'model_state_dict': UNet state dict}; the restorer stays in eval mode"""
+        print(f"Loading pretrained model from local path: {self.config.pretrained_restoration_model_path}")
+        try:
+            checkpoint_path = Path(self.config.pretrained_restoration_model_path).absolute()
+            checkpoint = torch.load(checkpoint_path, map_location="cpu")
+            base_net = UNet(self.config.pretrained_restoration_model_configuration)
+            base_net.load_state_dict(checkpoint['model_state_dict'])
+            base_net.to(self.device)
+            self.pretrained_restoration_model = RestorationWrapper(base_net)
+            self.pretrained_restoration_model.eval()
+            print("Successfully loaded pretrained model from local path")
+        except Exception as e:
+            raise RuntimeError(f"Failed to load model from local path: {str(e)}")
+
+    def train(self, mode: bool = True):
+        # nn.Module.train() would flip the frozen restorer into train mode; the reference never calls it on the
+        # model during training (its loop method shadows it), so the restorer stays in eval mode here too
+        super().train(mode)
+        self.pretrained_restoration_model.eval()
+        return self
+
+    def forward(self, masked_spec_mag_norm: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """[B,1,F,T] x 2 -> w_mat [B,n_dirs,F,T]   (nppc_model.py:119-145)"""
+        pred = self.get_pred_spec_mag_norm(masked_spec_mag_norm, mask)
+        return self.pc_wrapper(torch.cat((masked_spec_mag_norm, pred), dim=1), mask)
+
+    def get_pred_spec_mag_norm(self, masked_spec_mag_log, mask):
+        """frozen restorer under no_grad (nppc_model.py:147-159).  The reference evaluates it twice per step on the
+        same input (forward + base_step); the second call here returns the first call's result."""
+        key = (masked_spec_mag_log.data_ptr(), masked_spec_mag_log._version, tuple(masked_spec_mag_log.shape),
+               mask.data_ptr(), mask._version, self.pretrained_restoration_model.net.engine().fp.version()
+               if masked_spec_mag_log.is_cuda else None)
+        if self._memo is not None and self._memo[0] == key:
+            return self._memo[1]
+        with torch.no_grad():
+            pred = self.pretrained_restoration_model(masked_spec_mag_log, mask)
+        self._memo = (key, pred)
+        return pred

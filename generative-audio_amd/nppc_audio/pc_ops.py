@@ -55,7 +55,7 @@ class NPPCLoss(torch.autograd.Function):
     (reconst_err [B], objective [], err_norm, err_proj_re, err_proj_im, err_proj_mag, w_norms, second_moment_mse)."""
 
     @staticmethod
-    def forward(ctx, w_mat, gt, pred, lam):
+    def forward(ctx, w_mat, gt, pred, lam, eps=1e-8, eps_in_norms=0):
         H.require_gpu()
         w = w_mat.contiguous().float()
         gt, pred = gt.contiguous().float(), pred.contiguous().float()
@@ -70,7 +70,8 @@ class NPPCLoss(torch.autograd.Function):
         pr, pi, pm, wn, sm = f(B, K), f(B, K), f(B, K), f(B, K), f(B, K)
         coefA = torch.empty(B, K, 4, dtype=torch.float64, device=dev)
         coefE = torch.empty(B, K, 2, dtype=torch.float64, device=dev)
-        H.call("nppc_loss_solve", G, err_norm, pr, pi, pm, wn, reconst, sm, coefA, coefE, B, K, s)
+        H.call("nppc_loss_solve_eps", G, err_norm, pr, pi, pm, wn, reconst, sm, coefA, coefE, B, K, float(eps),
+               int(eps_in_norms), s)
         objective = reconst.mean() + lam * sm.mean()
         ctx.save_for_backward(w, gt, pred, coefA, coefE)
         ctx.lam = float(lam)
@@ -89,7 +90,7 @@ class NPPCLoss(torch.autograd.Function):
         H.call("nppc_loss_bwd_coef", coefA, coefE, grec, go / B, go * ctx.lam / (B * K), M1, B, K, s)
         dw = torch.empty_like(w)
         H.call("nppc_combine", w, M1, None, None, gt, pred, dw, B, K, N, s)
-        return dw, None, None, None
+        return dw, None, None, None, None, None
 
 
 def second_moment_weight(step, grace, lam):
@@ -97,3 +98,17 @@ def second_moment_weight(step, grace, lam):
     v = -1 + 2 * step / grace
     v = max(min(v, 1), 1e-6)
     return v * lam
+
+
+def planes(x):
+    """real [B, K, ...] -> complex-layout [B, K, 2, ...] with a zero imaginary plane (memory plumbing only):
+    the Gram-Schmidt / loss kernels are written for complex vectors; a real vector is the special case im = 0."""
+    z = torch.zeros(x.shape[0], x.shape[1], 2, *x.shape[2:], dtype=torch.float32, device=x.device)
+    z[:, :, 0].copy_(x)
+    return z
+
+
+def gram_schmidt_to_spec_mag(x: torch.Tensor) -> torch.Tensor:
+    """inpainting/nppc/pc_wrapper.py:43-59 on [B, K, F, T]: sequential projections onto the detached unit vectors,
+    no epsilon.  With zero imaginary parts the complex kernel's conjugate coefficient is the real dot product."""
+    return GramSchmidtCRM.apply(planes(x))[:, :, 0]

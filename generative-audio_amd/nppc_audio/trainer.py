@@ -148,6 +148,7 @@ class HipAdam(optim.Optimizer):
                 H.call("nppc_adam_step", p.data, g, st["exp_avg"], st["exp_avg_sq"], p.numel(), float(group["lr"]),
                        float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(st["step"]),
                        float(self.grad_scale), s)
+                torch.autograd.graph.increment_version(p)       # written through a raw pointer: tell the engines
         return loss
 
 
@@ -186,12 +187,19 @@ class FlatAdamStepper:
             st["exp_avg"] = self.m[o:o + k].view(shp)
             st["exp_avg_sq"] = self.v[o:o + k].view(shp)
 
-    def step(self, gflat, grad_scale=1.0):
+    def step(self, gflat, grad_scale=1.0, clip=None):
+        """clip = (device double holding sum(g^2), max_norm): clip_grad_norm_ folded into the same kernel"""
         self.t += 1
         g = self.group
         b1, b2 = g["betas"]
-        H.call("nppc_adam_step", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]), float(b1),
-               float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), H.stream())
+        if clip is None:
+            H.call("nppc_adam_step", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]), float(b1),
+                   float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), H.stream())
+        else:
+            H.call("nppc_adam_step_clip", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]),
+                   float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), clip[0],
+                   float(clip[1]), H.stream())
+        torch.autograd.graph.increment_version(self.eng.fp.flat)   # packed copies of the weights are stale now
         for _, p in self.eng.fp.named:
             self.opt.state[p]["step"].fill_(float(self.t))
 

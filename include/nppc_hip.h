@@ -148,12 +148,58 @@ int nppc_gs_solve(const double* G, double* C, double* Ch, int B, int K, int KV, 
 int nppc_gs_bwd_solve(const double* G, const double* P, const double* Ch, double* D, int B, int K, int KV, void* stream);
 int nppc_loss_solve(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
                     float* reconst, float* sm, double* coefA, double* coefE, int B, int K, void* stream);
+int nppc_loss_solve_eps(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
+                        float* reconst, float* sm, double* coefA, double* coefE, int B, int K, double eps, int eps_in_norms,
+                        void* stream);
 int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* grec, float gobj_over_B, float gsm, double* M1,
                        int B, int K, void* stream);
 
 /* ---- optimizer: torch.optim.Adam (nppc_audio/trainer.py:64-69,102-104) -------------------------------------- */
 int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                    double wd, int step, double gscale, void* stream);
+
+/* clip_grad_norm_(max_norm) + Adam without a host round trip (inpainting/trainer/nppc_trainer.py:149-154):
+ * nppc_sumsq accumulates sum(g^2) into a zeroed device double, nppc_adam_step_clip reads it. */
+int nppc_sumsq(const float* g, long n, double* out, void* stream);
+int nppc_adam_step_clip(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                        double wd, int step, double gscale, const double* sumsq, double max_norm, void* stream);
+
+/* ---- inpainting sibling: U-Net on haloed NHWC activations ------------------------------------------------------
+ * nppc_audio/inpainting/networks/unet.py:247-313, tmp_utils.py:8-99 (conv3x3 + BatchNorm2d + LeakyReLU(0.2),
+ * MaxPool2d(2), bilinear x2 align_corners + pad + cat, conv1x1), utils.py:273-306 (log-magnitude, batch-global
+ * mean / unbiased std), inpainting/nppc/pc_wrapper.py:75-84 and unet.py:299-312 (mask blending).
+ * Activations: X[(b*(H+2)+y)*(W+2)+x][ld], zero halo, zero guard rows; see csrc/unet.hip. */
+int nppc_logmag(const float* spec, float* out, long out_bstride, int B, long FT, double* st, void* stream);
+int nppc_standardize(float* a, float* b_or_null, long bstride, int B, long FT, const double* st, float* mean_std, void* stream);
+int nppc_unet_stage_map(int prec, const float* src, long src_bstride, void* dst, long ld, int c, int B, int H, int W,
+                        void* stream);
+int nppc_conv_pack(int prec, const float* w, void* wf, void* wb, int Cout, int Cin, int ksize, int Np, int Cinp, int Mb,
+                   int Coutp, void* stream);
+int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
+                  const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream);
+int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* slabs, int M, int N, int B, int H, int W,
+                    int ksize, int ksplit, void* stream);
+int nppc_conv_wgrad_reduce(const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize, void* stream);
+int nppc_bn_stats(int prec, const void* X, long ld, long P, int C, double* st, void* stream);
+int nppc_bn_finalize(const double* st, const float* gamma, const float* beta, float* rmean, float* rvar, float* ss, int C,
+                     double n, float eps, float momentum, int train, void* stream);
+int nppc_bn_act(int prec, const void* X, long ldx, void* Y, long ldy, const float* ss, int C, int B, int H, int W, float slope,
+                void* stream);
+int nppc_bn_bwd(int prec, const void* dyA, long ldA, const void* dyB, long ldB, const void* Y, long ldy, const void* X, long ldx,
+                const float* ss, double* S, void* dX, long lddx, float* dgamma, float* dbeta, int C, int B, int H, int W,
+                float slope, void* stream);
+int nppc_maxpool2(int prec, const void* X, long ldx, void* Y, long ldy, unsigned char* idx, int C, int B, int H, int W,
+                  void* stream);
+int nppc_maxpool2_bwd(int prec, const void* dY, long ldy, const unsigned char* idx, void* dX, long ldx, int C, int B, int H, int W,
+                      void* stream);
+int nppc_upsample2(int prec, const void* X, long ldx, void* Y, long ldy, int C, int B, int Hi, int Wi, int Ht, int Wt,
+                   void* stream);
+int nppc_upsample2_bwd(int prec, const void* dY, long ldy, void* dX, long ldx, int C, int B, int Hi, int Wi, int Ht, int Wt,
+                       void* stream);
+int nppc_unet_out(int prec, const void* raw, long ld, const float* mask, const float* xin, long xin_bstride, float* out,
+                  long out_pstride, int K, int B, int H, int W, int mode, void* stream);
+int nppc_unet_out_bwd(int prec, const float* dout, long dout_pstride, const float* mask, void* draw, long ld, int K, int B,
+                      int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,58 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
     assert abs(np.sqrt(nn_g) - meta["g500.grad_total_l2"]) < (2e-3 if fp32 else 1e-1) * meta["g500.grad_total_l2"]
     # the frozen restorer receives no gradient (trainer.py:66-69 hands its parameters to Adam anyway)
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("pretrained_restoration_model"))
+
+
+class _Mem(torch.utils.data.Dataset):
+    def __init__(self, noisy, clean):
+        self.noisy, self.clean = noisy, clean
+
+    def __len__(self):
+        return self.noisy.shape[0]
+
+    def __getitem__(self, i):
+        return self.noisy[i], self.clean[i]
+
+
+@pytest.mark.parametrize("name,opt", [("g0_tiny", "Adam"), ("g2_k5", "Adam"), ("g0_tiny", "AdamW")])
+def test_two_optimizer_steps_through_the_trainer(name, opt, tmp_path):
+    """NPPCAudioTrainer.train_step x 2 at steps 500, 501 against the reference's weights after one and two
+    Adam steps (goldens adam1.*, adam2.*).  'Adam' takes the flat-buffer HIP optimizer, 'AdamW' (weight_decay 0:
+    the same arithmetic) goes through .grad and torch's own optimizer -- both must see re-packed weights in step 2."""
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    z, meta = load(name)
+    c = meta["config"]
+    model, wts = build_model(c, "fp32", str(tmp_path))
+    mc = model.config
+    cfg = NPPCAudioTrainerConfig(
+        nppc_model_configuration=mc, data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+        data_loader_configuration=dict(batch_size=c["B"], num_workers=0, pin_memory=False, shuffle=False),
+        optimizer_configuration=dict(type=opt, args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
+        device="cuda")
+    noisy, clean = torch.from_numpy(z["noisy"]), torch.from_numpy(z["clean"])
+    tr = NPPCAudioTrainer(cfg, dataset=_Mem(noisy, clean))
+    tr.nppc_model.load_state_dict(wts, strict=True)
+    tr.nppc_model.to("cuda")
+    batch = (noisy.cuda(), clean.cuda())
+    params = dict(tr.nppc_model.named_parameters())
+    for it, step in ((1, 500), (2, 501)):
+        tr.step = step
+        _, obj, _ = tr.train_step(batch)
+        torch.cuda.synchronize()
+        if it == 2:
+            assert abs(float(obj) - meta["adam1.objective_next"]) < 5e-5
+        checked = 0
+        for k in z.files:
+            if not k.startswith(f"adam{it}."):
+                continue
+            n = k[len(f"adam{it}."):]
+            got = params[n].detach().cpu().numpy().reshape(-1)[:4096]
+            w0 = W.make_weights({n: tuple(params[n].shape)}, c["seed"])[n].reshape(-1)[:4096]
+            d = np.abs((got - w0) - (z[k] - w0))
+            # the update is ~lr per element; elements whose gradient sits at the fp32 noise floor of the
+            # ill-conditioned real/imag branches may take a different step (see the gradient test above)
+            lim = 0.05 * 1e-4 * it + 1e-9
+            loose = "_real." in n or "_imag." in n
+            assert (d > lim).mean() <= (0.05 if loose else 0.002) and np.median(d) < lim, (it, n, float(d.max()))
+            checked += 1
+        assert checked >= 6
