@@ -499,7 +499,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                long ldb, float* __restrict__ C, long ldc, long slab_stride,
-                                                               long Rz) {
+                                                               long Rz, int ntap, int Wp, int shift_a) {
   constexpr int BM = 128, BR = 64;
   constexpr int RSA = BM + 8, RSB = BN + 8;                 // LDS row strides (elements): 16-byte aligned rows
   constexpr int WN = BN / 2;                                // columns per wave (2x2 waves)
@@ -508,9 +508,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const long m0 = (long)blockIdx.x * BM, n0 = (long)blockIdx.y * BN;
-  const long rbase = (long)blockIdx.z * Rz;
-  const bf16_t* Ab = A + rbase * lda + m0;
-  const bf16_t* Bb = B + rbase * ldb + n0;
+  // blockIdx.z = tap * ksplit + slice: tap t reads B (or A, shift_a) shifted by (t/3 - 1) * Wp + (t%3 - 1) rows (3x3 convolution
+  // weight gradient: nine row-shifted products in one launch); ntap == 1 is the plain split-K GEMM
+  const int ksl = gridDim.z / ntap, tap = blockIdx.z / ksl;
+  const long rbase = (long)(blockIdx.z % ksl) * Rz;
+  const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
+  const bf16_t* Ab = A + (rbase + (shift_a ? boff : 0)) * lda + m0;
+  const bf16_t* Bb = B + (rbase + (shift_a ? 0 : boff)) * ldb + n0;
   float* Cz = C + (size_t)blockIdx.z * slab_stride;
 
   // staging: A tile 64 rows x 16 chunks (16 B) = 1024 chunks -> 4 per thread; B tile 64 x BN/8 chunks
@@ -605,20 +609,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
 
 // C_slab[z] [M][N] = A[rows slice z][M]^T * B[rows slice z][N]  (bf16 operands, fp32 slabs).  M % 128 == 0,
 // N % 64 == 0, R % (64*ksplit) == 0, lda/ldb multiples of 8.
-extern "C" int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
-                                   int ksplit, void* stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1) return NPPC_EBADARG;
+static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
+                     int ntap, int Wp, int shift_a, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (N % 128 == 0) {
-    dim3 grid(M / 128, N / 128, ksplit);
+    dim3 grid(M / 128, N / 128, ksplit * ntap);
     hipLaunchKernelGGL(gemm_tn_tiled_kernel<128>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                       (long)M * ldc, R / ksplit);
+                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a);
   } else {
-    dim3 grid(M / 128, N / 64, ksplit);
+    dim3 grid(M / 128, N / 64, ksplit * ntap);
     hipLaunchKernelGGL(gemm_tn_tiled_kernel<64>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                       (long)M * ldc, R / ksplit);
+                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a);
   }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
+}
+
+extern "C" int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
+                                   int ksplit, void* stream) {
+  return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream);
+}
+
+// Nine row-shifted TN products in one launch (3x3 convolution weight gradient, csrc/unet.hip):
+//   C_slab[t * ksplit + z][m][n] = sum_{r in slice z} A[r][m] * B[r + off_t][n],  off_t = (t/3 - 1) * Wp + (t%3 - 1)
+// (shift_a != 0: the shift is applied to A's rows instead: sum_r A[r + off_t][m] * B[r][n])
+extern "C" int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N,
+                                        long R, int ksplit, int Wp, int shift_a, void* stream) {
+  return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 9, Wp, shift_a, stream);
 }

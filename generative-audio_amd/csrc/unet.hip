@@ -16,12 +16,44 @@
 
 namespace {
 
+// 32-bit arithmetic: the host entry points reject P >= 2^31 (64-bit integer division has no hardware support)
 __device__ __forceinline__ bool interior(long p, long P, int H, int W) {
   if (p >= P) return false;
-  const int Wp = W + 2, Hp = H + 2;
-  const int x = (int)(p % Wp);
-  const int y = (int)((p / Wp) % Hp);
-  return x >= 1 && x <= W && y >= 1 && y <= H;
+  const unsigned Wp = W + 2, Hp = H + 2, pu = (unsigned)p;
+  const unsigned row = pu / Wp;
+  const unsigned x = pu - row * Wp;
+  const unsigned y = row % Hp;
+  return x >= 1 && x <= (unsigned)W && y >= 1 && y <= (unsigned)H;
+}
+
+// 8 consecutive channels of one pixel as one (bf16) or two (f32) 16-byte accesses; callers guarantee 16-byte alignment
+// (row widths and channel offsets are multiples of 8)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+  u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  u.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+  u.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<float4*>(p + 4) = float4{v[4], v[5], v[6], v[7]};
 }
 
 // ------------------------------------------------------------------------------------------------ convolution
@@ -35,8 +67,13 @@ struct ConvArgs {
   float slope;
   long P;                             // haloed pixel rows B*(H+2)*(W+2)
   int H, W, Cin, Cout, ntap;          // Cin % 32 == 0
-  int tapoff[9];
 };
+
+// row offset of tap t: (dy, dx) = (t/3 - 1, t%3 - 1) for a 3x3 kernel, 0 for 1x1 (arithmetic on a uniform value:
+// a dynamically indexed array in the by-value argument struct would be copied to scratch / LDS)
+__device__ __forceinline__ int tap_offset(const ConvArgs& g, int t) {
+  return g.ntap == 9 ? (t / 3 - 1) * (g.W + 2) + (t % 3 - 1) : 0;
+}
 
 // 256 threads = 4 waves stacked over rows; wave tile 32 x 64, block tile 128 rows x 64 output channels.
 template <typename T>
@@ -57,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs g) {
   frag a0[2], b0[4], a1[2], b1[4];
   int tap = 0, cc = 0;   // position of the NEXT k-step to load
   auto ld = [&](frag(&a)[2], frag(&b)[4], int kk) {
-    const long aoff = (long)g.tapoff[tap] * g.lda + 32 * cc;
+    const long aoff = (long)tap_offset(g, tap) * g.lda + 32 * cc;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) a[mi] = load_frag<T>(ap + (long)16 * mi * g.lda + aoff);
 #pragma unroll
@@ -108,6 +145,124 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs g) {
     }
 }
 
+// LDS-staged variant (Cin a multiple of the 128-byte stage: 64 bf16 / 32 f32).  256 threads = 2 x 2 waves, block tile
+// 128 rows x BN output channels, one 128-byte K slice of ONE tap per stage, double-buffered LDS with register staging
+// (next stage's global loads are issued before the MFMAs and written to LDS after them), one barrier per stage.
+// LDS rows are 128 B = 8 chunks of 16 B stored at slot (chunk ^ (row & 7)): staging writes and fragment reads are
+// bank-conflict free.  The A tile of a stage is the pixel rows shifted by that tap's offset.
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
+  typedef typename Frag<T>::type frag;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  constexpr int KS = BK / 32;
+  constexpr int NJ = BN / 32;                                      // 16-column MFMA tiles per wave
+  constexpr int NBI = BN / 32;                                     // B staging chunks per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][(128 + BN) * 128];   // [buffer][A rows | B rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * BN;
+  const long ldw = (long)g.ntap * g.Cin;
+  const int srow = tid >> 3, sc = tid & 7;
+  const T* ga = reinterpret_cast<const T*>(g.A) + (m0 + srow) * g.lda + sc * EPC;
+  const T* gb = reinterpret_cast<const T*>(g.Wp) + (long)(n0 + srow) * ldw + sc * EPC;
+  const int soff = srow * 128 + ((sc ^ (srow & 7)) << 4);
+  const int kc = g.Cin / BK;
+  const int nstage = g.ntap * kc;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // named registers: an indexed array would be demoted to scratch / LDS
+  int tap = 0, cc = 0;
+#define CGLOAD(sidx)                                                                   \
+  {                                                                                    \
+    const T* pa = ga + (long)tap_offset(g, tap) * g.lda + cc * BK;                     \
+    ra0 = *reinterpret_cast<const uint4*>(pa);                                         \
+    ra1 = *reinterpret_cast<const uint4*>(pa + 32 * g.lda);                            \
+    ra2 = *reinterpret_cast<const uint4*>(pa + 64 * g.lda);                            \
+    ra3 = *reinterpret_cast<const uint4*>(pa + 96 * g.lda);                            \
+    const T* pb = gb + (long)(sidx) * BK;                                              \
+    rb0 = *reinterpret_cast<const uint4*>(pb);                                         \
+    rb1 = *reinterpret_cast<const uint4*>(pb + 32 * ldw);                              \
+    if constexpr (NBI == 4) {                                                          \
+      rb2 = *reinterpret_cast<const uint4*>(pb + 64 * ldw);                            \
+      rb3 = *reinterpret_cast<const uint4*>(pb + 96 * ldw);                            \
+    }                                                                                  \
+    if (++cc == kc) { cc = 0; ++tap; }                                                 \
+  }
+#define CLSTORE(buf)                                                                   \
+  {                                                                                    \
+    *reinterpret_cast<uint4*>(&lds[buf][soff]) = ra0;                                  \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 32 * 128]) = ra1;                       \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 64 * 128]) = ra2;                       \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 96 * 128]) = ra3;                       \
+    *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff]) = rb0;                      \
+    *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 32 * 128]) = rb1;           \
+    if constexpr (NBI == 4) {                                                          \
+      *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 64 * 128]) = rb2;         \
+      *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 96 * 128]) = rb3;         \
+    }                                                                                  \
+  }
+  auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
+    if constexpr (sizeof(T) == 2) {
+      const int c = 4 * ks + q;
+      return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+      const int c0 = 2 * q, c1 = 2 * q + 1;
+      const float4 lo = *reinterpret_cast<const float4*>(base + row * 128 + ((c0 ^ (row & 7)) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(base + row * 128 + ((c1 ^ (row & 7)) << 4));
+      frag f;
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+      return f;
+    }
+  };
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  CGLOAD(0)
+  CLSTORE(0)
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstage) CGLOAD(s + 1)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      frag af[4], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lfrag(lds[buf], wm * 64 + 16 * i + n, ks);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = lfrag(lds[buf] + 128 * 128, wn * (BN / 2) + 16 * j + n, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bf[j], acc[i][j]);
+    }
+    if (s + 1 < nstage) CLSTORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef CGLOAD
+#undef CLSTORE
+  T* C = reinterpret_cast<T*>(g.C);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = m0 + wm * 64 + 16 * i + 4 * q + r;
+      if (!interior(row, g.P, g.H, g.W)) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (BN / 2) + 16 * j + n;
+        if (col >= g.Cout) continue;
+        float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
+        if (g.scale) {
+          v = v * g.scale[col] + g.shift[col];
+          v = v > 0.f ? v : g.slope * v;
+        }
+        C[row * g.ldc + col] = from_f32<T>(v);
+      }
+    }
+}
+
 // weight [Cout][Cin][kh][kw] fp32 -> forward pack  Wf[Np][ntap][Cinp]       (Wf[co][t][ci] = w[co][ci][t])
 //                                  -> backward pack Wb[Cinp64][ntap][Coutp]  (Wb[ci][t][co] = w[co][ci][ntap-1-t])
 template <typename T>
@@ -141,10 +296,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ X, 
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
   if (r < rl)
     for (long p = p0 + r; p < p1; p += rl) {
-      const T* x = X + p * ld + g8 * 8;
+      float xv[8];
+      load8<T>(X + p * ld + g8 * 8, xv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const double v = (double)to_f32<T>(x[i]);
+        const double v = (double)xv[i];
         s1[i] += v;
         s2[i] += v * v;
       }
@@ -197,14 +353,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ X, lo
   const long p = i / cg;
   const int c8 = (int)(i % cg) * 8;
   if (!interior(p, P, H, W)) return;
-  const T* x = X + p * ldx + c8;
-  T* y = Y + p * ldy + c8;
+  float xv[8], yv[8];
+  load8<T>(X + p * ldx + c8, xv);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float v = to_f32<T>(x[k]) * ss[c8 + k] + ss[C + c8 + k];
-    v = v > 0.f ? v : slope * v;
-    y[k] = from_f32<T>(v);
+    const float v = xv[k] * ss[c8 + k] + ss[C + c8 + k];
+    yv[k] = v > 0.f ? v : slope * v;
   }
+  store8<T>(Y + p * ldy + c8, yv);
 }
 
 // g = (dyA + dyB) * leaky'(y);  S[c] += sum g,  S[C + c] += sum g * xhat      (fp64 atomics), xhat = (x - mean) rstd
@@ -229,16 +385,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   if (r < rl)
     for (long p = p0 + r; p < p1; p += rl) {
       if (!interior(p, P, H, W)) continue;
-      const T* a = dyA + p * ldA + g8 * 8;
-      const T* b = dyB ? dyB + p * ldB + g8 * 8 : nullptr;
-      const T* y = Y + p * ldy + g8 * 8;
-      const T* x = X + p * ldx + g8 * 8;
+      float av[8], bv[8], yv[8], xv[8];
+      load8<T>(dyA + p * ldA + g8 * 8, av);
+      if (dyB) {
+        load8<T>(dyB + p * ldB + g8 * 8, bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] += bv[i];
+      }
+      load8<T>(Y + p * ldy + g8 * 8, yv);
+      load8<T>(X + p * ldx + g8 * 8, xv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float gq = to_f32<T>(a[i]) + (b ? to_f32<T>(b[i]) : 0.f);
-        if (!(to_f32<T>(y[i]) > 0.f)) gq *= slope;
+        float gq = av[i];
+        if (!(yv[i] > 0.f)) gq *= slope;
         s1[i] += gq;
-        s2[i] += gq * ((to_f32<T>(x[i]) - mean[i]) * rstd[i]);
+        s2[i] += gq * ((xv[i] - mean[i]) * rstd[i]);
       }
     }
 #pragma unroll
@@ -271,20 +432,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const long p = i / cg;
   const int c8 = (int)(i % cg) * 8;
   if (!interior(p, P, H, W)) return;
-  const T* a = dyA + p * ldA + c8;
-  const T* b = dyB ? dyB + p * ldB + c8 : nullptr;
-  const T* y = Y + p * ldy + c8;
-  const T* x = X + p * ldx + c8;
-  T* d = dX + p * lddx + c8;
+  const double invn = 1.0 / n;
+  float av[8], bv[8], yv[8], xv[8], dv[8];
+  load8<T>(dyA + p * ldA + c8, av);
+  if (dyB) {
+    load8<T>(dyB + p * ldB + c8, bv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) av[k] += bv[k];
+  }
+  load8<T>(Y + p * ldy + c8, yv);
+  load8<T>(X + p * ldx + c8, xv);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c8 + k;
-    float gq = to_f32<T>(a[k]) + (b ? to_f32<T>(b[k]) : 0.f);
-    if (!(to_f32<T>(y[k]) > 0.f)) gq *= slope;
-    const float xh = (to_f32<T>(x[k]) - ss[2 * C + c]) * ss[3 * C + c];
-    const float m1 = (float)(S[c] / n), m2 = (float)(S[C + c] / n);
-    d[k] = from_f32<T>(ss[c] * (gq - m1 - xh * m2));
+    float gq = av[k];
+    if (!(yv[k] > 0.f)) gq *= slope;
+    const float xh = (xv[k] - ss[2 * C + c]) * ss[3 * C + c];
+    const float m1 = (float)(S[c] * invn), m2 = (float)(S[C + c] * invn);
+    dv[k] = ss[c] * (gq - m1 - xh * m2);
   }
+  store8<T>(dX + p * lddx + c8, dv);
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -468,11 +635,11 @@ __global__ __launch_bounds__(256) void wgrad_simple_kernel(const T* __restrict__
 
 // dW[co][ci][t] = sum_s slabs[t][s][co][ci]     (torch layout [Cout][Cin][kh][kw])
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, long slab_stride, long ldc, float* __restrict__ dW,
-                                    int Cout, int Cin, int ntap) {
+                                    int Cout, int Cin, int ntap, int transposed) {
   const long total = (long)Cout * Cin * ntap;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), t = (int)(i / ((long)Cin * Cout));
-    const float* s = slabs + (size_t)t * S * slab_stride + (long)co * ldc + ci;
+    const float* s = slabs + (size_t)t * S * slab_stride + (transposed ? (long)ci * ldc + co : (long)co * ldc + ci);
     double a = 0.0;
     for (int k = 0; k < S; ++k) a += (double)s[(size_t)k * slab_stride];
     dW[((long)co * Cin + ci) * ntap + t] = (float)a;
@@ -595,13 +762,26 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
                   const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream) {
   if (!A || !Wp || !C || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
   if (Cin % 32 || Np % 64 || Cout > Np || (ksize != 1 && ksize != 3) || (scale && !shift)) return NPPC_EUNSUPPORTED;
+  if ((long)B * (H + 2) * (W + 2) >= (1L << 31)) return NPPC_EUNSUPPORTED;
   ConvArgs g;
   g.A = A; g.lda = lda; g.Wp = Wp; g.C = C; g.ldc = ldc; g.bias = bias; g.scale = scale; g.shift = shift; g.slope = slope;
   g.P = (long)B * (H + 2) * (W + 2);
   g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ntap = ksize * ksize;
-  for (int t = 0; t < 9; ++t) g.tapoff[t] = 0;
-  if (ksize == 3)
-    for (int t = 0; t < 9; ++t) g.tapoff[t] = (t / 3 - 1) * (W + 2) + (t % 3 - 1);
+  const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32)) {
+    if (Np % 128 == 0) {
+      dim3 grid(ceil_div(g.P, 128), Np / 128);
+      if (prec == NPPC_PREC_BF16) hipLaunchKernelGGL((conv_tiled_kernel<bf16_t, 128>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((conv_tiled_kernel<float, 128>), grid, dim3(256), 0, st, g);
+    } else {
+      dim3 grid(ceil_div(g.P, 128), Np / 64);
+      if (prec == NPPC_PREC_BF16) hipLaunchKernelGGL((conv_tiled_kernel<bf16_t, 64>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((conv_tiled_kernel<float, 64>), grid, dim3(256), 0, st, g);
+    }
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
   dim3 grid(ceil_div(g.P, 128), Np / 64);
   LAUNCH_T(prec, conv_kernel, grid, g);
   return NPPC_OK;
@@ -636,6 +816,7 @@ int nppc_bn_act(int prec, const void* X, long ldx, void* Y, long ldy, const floa
                 void* stream) {
   if (!X || !Y || !ss || C % 8) return NPPC_EBADARG;
   const long P = (long)B * (H + 2) * (W + 2);
+  if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
   LAUNCH_T(prec, bn_act_kernel, dim3(ceil_div(P * (C / 8), 256)), (const TT*)X, ldx, (TT*)Y, ldy, ss, C, P, H, W, slope);
   return NPPC_OK;
 }
@@ -645,6 +826,7 @@ int nppc_bn_bwd(int prec, const void* dyA, long ldA, const void* dyB, long ldB, 
                 float slope, void* stream) {
   if (!dyA || !Y || !X || !ss || !S || !dX || !dgamma || !dbeta || C % 8 || C / 8 > 256) return NPPC_EBADARG;
   const long P = (long)B * (H + 2) * (W + 2);
+  if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
   const int rpb = 1024;
   const double n = (double)B * H * W;
   if (hipMemsetAsync(S, 0, sizeof(double) * 2 * C, (hipStream_t)stream) != hipSuccess) return NPPC_ELAUNCH;
@@ -692,6 +874,9 @@ int nppc_upsample2_bwd(int prec, const void* dY, long ldy, void* dX, long ldx, i
 // Weight gradient of a ksize x ksize convolution:  slabs[t][s][m][n] = sum_{p in slice s} dY[p][m] * X[p + off(t)][n].
 // bf16 with M % 128 == 0 (or M == 64: computed as 128 with the upper half discarded), N % 64 == 0 runs on the MFMA
 // TN GEMM; everything else on the exact-f32 tile kernel.  Rows beyond P must be readable and dY zero there.
+// slab orientation chosen by nppc_conv_wgrad (bf16, 3x3): 1 = slabs hold dW^T [N = Cin][M = Cout]
+int nppc_conv_wgrad_transposed(int M, int N) { return (M % 128 != 0 && N % 128 == 0) ? 1 : 0; }
+
 int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* slabs, int M, int N, int B, int H, int W,
                     int ksize, int ksplit, void* stream) {
   if (!dY || !X || !slabs || M % 64 || N % 64 || ksplit < 1 || (ksize != 1 && ksize != 3)) return NPPC_EBADARG;
@@ -699,31 +884,33 @@ int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx
   const int ntap = ksize * ksize;
   const int Mr = (M + 127) / 128 * 128;
   const long slab_stride = (long)Mr * N;
+  if (prec == NPPC_PREC_BF16) {
+    const long R = (P + 64L * ksplit - 1) / (64L * ksplit) * (64L * ksplit);
+    if (ksize == 3 && nppc_conv_wgrad_transposed(M, N))   // 64 output channels: put the wide side on the 128-row tile axis
+      return nppc_gemm_tn_splitk_taps(X, ldx, dY, lddy, slabs, M, N, M, R, ksplit, W + 2, 1, stream);
+    return ksize == 3 ? nppc_gemm_tn_splitk_taps(dY, lddy, X, ldx, slabs, N, Mr, N, R, ksplit, W + 2, 0, stream)
+                      : nppc_gemm_tn_splitk(dY, lddy, X, ldx, slabs, N, Mr, N, R, ksplit, stream);
+  }
+  if (prec != NPPC_PREC_F32) return NPPC_EBADARG;
   for (int t = 0; t < ntap; ++t) {
     const long off = ksize == 3 ? (long)(t / 3 - 1) * (W + 2) + (t % 3 - 1) : 0;
     float* out = slabs + (size_t)t * ksplit * slab_stride;
-    if (prec == NPPC_PREC_BF16) {
-      const long R = (P + 64L * ksplit - 1) / (64L * ksplit) * (64L * ksplit);
-      const int rc = nppc_gemm_tn_splitk(dY, lddy, (const bf16_t*)X + off * ldx, ldx, out, N, Mr, N, R, ksplit, stream);
-      if (rc != NPPC_OK) return rc;
-    } else if (prec == NPPC_PREC_F32) {
-      const long rps = ((P + ksplit - 1) / ksplit + 15) / 16 * 16;
-      hipLaunchKernelGGL(wgrad_simple_kernel<float>, dim3(M / 64, N / 64, ksplit), dim3(256), 0, (hipStream_t)stream,
-                         (const float*)dY, lddy, (const float*)X, ldx, off, out, (long)N, slab_stride, P, rps);
-      NPPC_CHECK_LAUNCH();
-    } else {
-      return NPPC_EBADARG;
-    }
+    const long rps = ((P + ksplit - 1) / ksplit + 15) / 16 * 16;
+    hipLaunchKernelGGL(wgrad_simple_kernel<float>, dim3(M / 64, N / 64, ksplit), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dY, lddy, (const float*)X, ldx, off, out, (long)N, slab_stride, P, rps);
+    NPPC_CHECK_LAUNCH();
   }
   return NPPC_OK;
 }
 
-int nppc_conv_wgrad_reduce(const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize, void* stream) {
+int nppc_conv_wgrad_reduce(int prec, const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize,
+                           void* stream) {
   if (!slabs || !dW || Cout > M || Cin > N) return NPPC_EBADARG;
   const int Mr = (M + 127) / 128 * 128;
   const long total = (long)Cout * Cin * ksize * ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, (long)Mr * N,
-                     (long)N, dW, Cout, Cin, ksize * ksize);
+  const int tr = prec == NPPC_PREC_BF16 && ksize == 3 && nppc_conv_wgrad_transposed(M, N);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, slabs, ksplit,
+                     tr ? (long)N * M : (long)Mr * N, tr ? (long)M : (long)N, dW, Cout, Cin, ksize * ksize, tr);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

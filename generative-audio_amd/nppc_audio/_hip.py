@@ -89,6 +89,7 @@ SIGS = {
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],
     "nppc_gemm_tn_splitk": [P, L, P, L, P, L, I, I, L, I, P],
+    "nppc_gemm_tn_splitk_taps": [P, L, P, L, P, L, I, I, L, I, I, I, P],
     "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],
@@ -116,7 +117,8 @@ SIGS = {
     "nppc_conv_pack": [I, P, P, P, I, I, I, I, I, I, I, P],
     "nppc_conv_fwd": [I, P, L, P, P, L, P, P, P, F, I, I, I, I, I, I, I, P],
     "nppc_conv_wgrad": [I, P, L, P, L, P, I, I, I, I, I, I, I, P],
-    "nppc_conv_wgrad_reduce": [P, I, I, I, P, I, I, I, P],
+    "nppc_conv_wgrad_transposed": [I, I],
+    "nppc_conv_wgrad_reduce": [I, P, I, I, I, P, I, I, I, P],
     "nppc_bn_stats": [I, P, L, L, I, P, P],
     "nppc_bn_finalize": [P, P, P, P, P, P, I, D, F, F, I, P],
     "nppc_bn_act": [I, P, L, P, L, P, I, I, I, I, F, P],

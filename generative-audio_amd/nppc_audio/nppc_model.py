@@ -68,9 +68,11 @@ class NPPCModel(nn.Module):
         """STFT + frozen restorer.  `forward` always recomputes (reuse=False) and leaves the result for the
         `get_pred_crm` / gt-mask calls that follow on the SAME tensor within the step."""
         H.require_gpu()
-        key = (noisy_waveform.data_ptr(), noisy_waveform._version, tuple(noisy_waveform.shape))
-        if reuse and self._memo is not None and self._memo[0] == key:
-            return self._memo[1]
+        # the memo holds the input tensor itself: identity + version is then a safe key (an address alone could be
+        # recycled by the caching allocator for the next batch)
+        m = self._memo
+        if reuse and m is not None and m[0] is noisy_waveform and m[1] == noisy_waveform._version:
+            return m[2]
         st = self.config.stft_configuration
         if st.win_length != st.nfft:
             raise NotImplementedError("win_length == nfft is the STFT configuration built for MI355X")
@@ -78,7 +80,7 @@ class NPPCModel(nn.Module):
         with torch.no_grad():
             pred_crm = self.pretrained_restoration_model(mag[:, None], re[:, None], im[:, None])
         out = dict(mag=mag, re=re, im=im, pred_crm=pred_crm)
-        self._memo = (key, out)
+        self._memo = (noisy_waveform, noisy_waveform._version, out)
         return out
 
     def forward(self, noisy_waveform: torch.Tensor) -> torch.Tensor:

@@ -23,8 +23,29 @@ IN_LD = 64          # the 1- or 2-channel net input is staged into a 64-wide zer
 OUT_LD = 64         # so is the K-channel output of the 1x1 convolution
 
 
+PROFILE = None      # bench hook: list of (kind, algorithmic flops, start event, end event)
+
+
 def rup(a, b):
     return (a + b - 1) // b * b
+
+
+class _timed:
+    """records a HIP-event pair on the current stream around the launches inside the block (bench only)"""
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, e1))
 
 
 class _Buf:
@@ -141,8 +162,9 @@ class UNetEngine:
         if ks == 3 and cinp != ldx:
             raise RuntimeError(f"{name}: input row width {ldx} != packed K {cinp}")
         ss = self.ss[name] if fold else None
-        H.call("nppc_conv_fwd", self.prec, x, ldx, self.wf[name], y, ldy, self.p(name + ".bias"),
-               ss, ss[cout:] if fold else None, LEAK, B, h, w, cinp, cout, np_, ks, H.stream())
+        with _timed("conv_fwd", 2.0 * B * h * w * cin * cout * ks * ks):
+            H.call("nppc_conv_fwd", self.prec, x, ldx, self.wf[name], y, ldy, self.p(name + ".bias"),
+                   ss, ss[cout:] if fold else None, LEAK, B, h, w, cinp, cout, np_, ks, H.stream())
 
     def _bn_train(self, conv_name, raw, cout, level, y, ldy):
         """batch statistics -> scale/shift (+ running update) -> LeakyReLU, output possibly a channel slice"""
@@ -265,16 +287,18 @@ class UNetEngine:
         S = self.ksplit[level]
         slabs = self._slabs(ks * ks * S * rup(M, 128) * N)
         s = H.stream()
-        H.call("nppc_conv_wgrad", self.prec, dy, lddy, x, ldx, slabs, M, N, B, h, w, ks, S, s)
-        H.call("nppc_conv_wgrad_reduce", slabs, S, M, N, self.g(name + ".weight"), cout, cin, ks, s)
+        with _timed("conv_wgrad", 2.0 * B * h * w * cin * cout * ks * ks):
+            H.call("nppc_conv_wgrad", self.prec, dy, lddy, x, ldx, slabs, M, N, B, h, w, ks, S, s)
+            H.call("nppc_conv_wgrad_reduce", self.prec, slabs, S, M, N, self.g(name + ".weight"), cout, cin, ks, s)
 
     def _conv_bwd_data(self, name, cin, cout, ks, dy, lddy, dx, lddx, level):
         """dX = transposed convolution of dY: the forward kernel on the flipped / transposed pack"""
         B = self.geo[0]
         h, w = self.lv[level]
         cinp, np_ = self._dims(name, cin, cout)
-        H.call("nppc_conv_fwd", self.prec, dy, lddy, self.wb[name], dx, lddx, None, None, None, LEAK, B, h, w, np_, cin, cinp,
-               ks, H.stream())
+        with _timed("conv_bwd_data", 2.0 * B * h * w * cin * cout * ks * ks):
+            H.call("nppc_conv_fwd", self.prec, dy, lddy, self.wb[name], dx, lddx, None, None, None, LEAK, B, h, w, np_, cin,
+                   cinp, ks, H.stream())
 
     def _double_conv_bwd(self, blk, dyA, ldA, dyB, ldB, need_dx):
         sv = self.saved["blocks"][blk]

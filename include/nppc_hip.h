@@ -71,6 +71,8 @@ int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long l
  * LDS tiles read back with ds_read_b64_tr_b16; M % 128 == 0, N % 64 == 0, R % (64*ksplit) == 0 */
 int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                         void* stream);
+int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
+                             int ksplit, int Wp, int shift_a, void* stream);
 int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
 int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
                     const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
@@ -179,7 +181,9 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
                   const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream);
 int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* slabs, int M, int N, int B, int H, int W,
                     int ksize, int ksplit, void* stream);
-int nppc_conv_wgrad_reduce(const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize, void* stream);
+int nppc_conv_wgrad_transposed(int M, int N);
+int nppc_conv_wgrad_reduce(int prec, const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize,
+                           void* stream);
 int nppc_bn_stats(int prec, const void* X, long ld, long P, int C, double* st, void* stream);
 int nppc_bn_finalize(const double* st, const float* gamma, const float* beta, float* rmean, float* rvar, float* ss, int C,
                      double n, float eps, float momentum, int train, void* stream);

@@ -99,7 +99,7 @@ def test_conv_forward_input_gradient_weight_gradient(pname, prec, dtype, tol, B,
     slabs = torch.empty(nt * ksplit * ((M + 127) // 128 * 128) * Cin, dtype=torch.float32, device="cuda")
     dW = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device="cuda")
     Hh.call("nppc_conv_wgrad", prec, DY.t, Np, X.t, Cin, slabs, M, Cin, B, H, W, ks, ksplit, s)
-    Hh.call("nppc_conv_wgrad_reduce", slabs, ksplit, M, Cin, dW, Cout, Cin, ks, s)
+    Hh.call("nppc_conv_wgrad_reduce", prec, slabs, ksplit, M, Cin, dW, Cout, Cin, ks, s)
     torch.cuda.synchronize()
     assert rel(dW.cpu(), wr.grad) < (tol if pname == "fp32" else 1e-2)
 
