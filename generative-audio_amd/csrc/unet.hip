@@ -349,9 +349,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
                                                      const float* __restrict__ ss, int C, long P, int H, int W, float slope) {
   const int cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long p = i / cg;
-  const int c8 = (int)(i % cg) * 8;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;      // host guarantees P * C / 8 < 2^32
+  const long p = i / (unsigned)cg;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
   if (!interior(p, P, H, W)) return;
   float xv[8], yv[8];
   load8<T>(X + p * ldx + c8, xv);
@@ -428,9 +428,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       dbeta[c] = (float)S[c];
     }
   const int cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long p = i / cg;
-  const int c8 = (int)(i % cg) * 8;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;      // host guarantees P * C / 8 < 2^32
+  const long p = i / (unsigned)cg;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
   if (!interior(p, P, H, W)) return;
   const double invn = 1.0 / n;
   float av[8], bv[8], yv[8], xv[8], dv[8];
@@ -460,11 +460,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
                                                       unsigned char* __restrict__ idx, int C, int B, int H, int W) {
   const int Ho = H / 2, Wo = W / 2, cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int c8 = (int)(i % cg) * 8;
-  long o = i / cg;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
+  unsigned o = i / (unsigned)cg;
   if (o >= (long)B * Ho * Wo) return;
-  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  const int xo = (int)(o % (unsigned)Wo), yo = (int)((o / (unsigned)Wo) % (unsigned)Ho), b = (int)(o / ((unsigned)Wo * (unsigned)Ho));
   const long pin = ((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1;
   const long pout = ((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1;
   const long offs[4] = {0, 1, (long)(W + 2), (long)(W + 3)};
@@ -487,11 +487,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dY, long ldy, const unsigned char* __restrict__ idx,
                                                           T* __restrict__ dX, long ldx, int C, int B, int H, int W) {
   const int Ho = H / 2, Wo = W / 2, cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int c8 = (int)(i % cg) * 8;
-  long o = i / cg;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
+  unsigned o = i / (unsigned)cg;
   if (o >= (long)B * Ho * Wo) return;
-  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  const int xo = (int)(o % (unsigned)Wo), yo = (int)((o / (unsigned)Wo) % (unsigned)Ho), b = (int)(o / ((unsigned)Wo * (unsigned)Ho));
   const long pin = ((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1;
   const long pout = ((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1;
   const long offs[4] = {0, 1, (long)(W + 2), (long)(W + 3)};
@@ -521,11 +521,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy, int C,
                                                        int B, int Hi, int Wi, int Ht, int Wt, int py, int px) {
   const int Ho = 2 * Hi, Wo = 2 * Wi, cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int c8 = (int)(i % cg) * 8;
-  long o = i / cg;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
+  unsigned o = i / (unsigned)cg;
   if (o >= (long)B * Ho * Wo) return;
-  const int xo = (int)(o % Wo), yo = (int)((o / Wo) % Ho), b = (int)(o / ((long)Wo * Ho));
+  const int xo = (int)(o % (unsigned)Wo), yo = (int)((o / (unsigned)Wo) % (unsigned)Ho), b = (int)(o / ((unsigned)Wo * (unsigned)Ho));
   int y0, y1, x0, x1;
   float ly0, ly1, lx0, lx1;
   bil(yo, Hi, Ho, y0, y1, ly0, ly1);
@@ -547,11 +547,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dY, long ldy, T* __restrict__ dX, long ldx,
                                                            int C, int B, int Hi, int Wi, int Ht, int Wt, int py, int px) {
   const int Ho = 2 * Hi, Wo = 2 * Wi, cg = C / 8;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const int c8 = (int)(i % cg) * 8;
-  long o = i / cg;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const int c8 = (int)(i % (unsigned)cg) * 8;
+  unsigned o = i / (unsigned)cg;
   if (o >= (long)B * Hi * Wi) return;
-  const int xi = (int)(o % Wi), yi = (int)((o / Wi) % Hi), b = (int)(o / ((long)Wi * Hi));
+  const int xi = (int)(o % (unsigned)Wi), yi = (int)((o / (unsigned)Wi) % (unsigned)Hi), b = (int)(o / ((unsigned)Wi * (unsigned)Hi));
   float wy[6], wx[6];
   int oy[6], ox[6];
 #pragma unroll
