@@ -507,15 +507,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][BR * RSA + BR * RSB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.x * BM, n0 = (long)blockIdx.y * BN;
-  // blockIdx.z = tap * ksplit + slice: tap t reads B (or A, shift_a) shifted by (t/3 - 1) * Wp + (t%3 - 1) rows (3x3 convolution
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear id order.
+  // All output tiles of one K slice read the same operand rows, so they are mapped to ONE XCD (slice = f(id % 8)):
+  // the slice is fetched from HBM once and the (M/128)*(N/BN)-fold re-reads hit that XCD's L2.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z % 8 == 0) {
+    const unsigned tiles = gridDim.x * gridDim.y;
+    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+    const unsigned xcd = lin & 7, j = lin >> 3;
+    bz = xcd + 8 * (j / tiles);
+    const unsigned t = j % tiles;
+    bx = t % gridDim.x;
+    by = t / gridDim.x;
+  }
+  const long m0 = (long)bx * BM, n0 = (long)by * BN;
+  // bz = tap * ksplit + slice: tap t reads B (or A, shift_a) shifted by (t/3 - 1) * Wp + (t%3 - 1) rows (3x3 convolution
   // weight gradient: nine row-shifted products in one launch); ntap == 1 is the plain split-K GEMM
-  const int ksl = gridDim.z / ntap, tap = blockIdx.z / ksl;
-  const long rbase = (long)(blockIdx.z % ksl) * Rz;
+  const int ksl = gridDim.z / ntap, tap = bz / ksl;
+  const long rbase = (long)(bz % ksl) * Rz;
   const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
   const bf16_t* Ab = A + (rbase + (shift_a ? boff : 0)) * lda + m0;
   const bf16_t* Bb = B + (rbase + (shift_a ? 0 : boff)) * ldb + n0;
-  float* Cz = C + (size_t)blockIdx.z * slab_stride;
+  float* Cz = C + (size_t)bz * slab_stride;
 
   // staging: A tile 64 rows x 16 chunks (16 B) = 1024 chunks -> 4 per thread; B tile 64 x BN/8 chunks
   constexpr int ACH = BM / 8, BCH = BN / 8;

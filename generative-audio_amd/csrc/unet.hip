@@ -161,8 +161,13 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][(128 + BN) * 128];   // [buffer][A rows | B rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.x * 128;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware order (grid.x is a multiple of 8): the gridDim.y channel tiles of one pixel tile run back to back on the
+  // SAME XCD, so the pixel rows are fetched from HBM once and re-read from that XCD's L2
+  const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned xcd = lin & 7, jj = lin >> 3;
+  const long m0 = (long)((jj / gridDim.y) * 8 + xcd) * 128;
+  const int n0 = (int)(jj % gridDim.y) * BN;
+  if (m0 >= g.P) return;
   const long ldw = (long)g.ntap * g.Cin;
   const int srow = tid >> 3, sc = tid & 7;
   const T* ga = reinterpret_cast<const T*>(g.A) + (m0 + srow) * g.lda + sc * EPC;
@@ -771,11 +776,11 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
   hipStream_t st = (hipStream_t)stream;
   if (Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32)) {
     if (Np % 128 == 0) {
-      dim3 grid(ceil_div(g.P, 128), Np / 128);
+      dim3 grid(round_up(ceil_div(g.P, 128), 8), Np / 128);
       if (prec == NPPC_PREC_BF16) hipLaunchKernelGGL((conv_tiled_kernel<bf16_t, 128>), grid, dim3(256), 0, st, g);
       else hipLaunchKernelGGL((conv_tiled_kernel<float, 128>), grid, dim3(256), 0, st, g);
     } else {
-      dim3 grid(ceil_div(g.P, 128), Np / 64);
+      dim3 grid(round_up(ceil_div(g.P, 128), 8), Np / 64);
       if (prec == NPPC_PREC_BF16) hipLaunchKernelGGL((conv_tiled_kernel<bf16_t, 64>), grid, dim3(256), 0, st, g);
       else hipLaunchKernelGGL((conv_tiled_kernel<float, 64>), grid, dim3(256), 0, st, g);
     }

@@ -9,7 +9,8 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_backward, lstm2_forward, padded_rows, rows_view, workspace
+from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, lstm2_backward, lstm2_forward, padded_rows,
+                       rows_view, workspace)
 
 TCN_HIDDEN = 512
 TCN_DILATIONS = (1, 2, 5, 9, 1, 2, 5, 9)
@@ -339,7 +340,10 @@ class FSNEngine:
                 self.g(dest[3]).copy_(self.g(dest[2]))
 
         if self.prec == H.PREC_BF16 and K4 % 128 == 0 and Hd % 64 == 0 and KX % 64 == 0:
-            S = 16
+            # 64 K-slices: (4H/128) * (H/128) * 64 = 2304 workgroups for 512 slots (16 slices = 576 left the second
+            # round of workgroups 1/8 full: 481 -> 674 TFLOP/s on the H x 4H products, tools/bench_tn.py)
+            S = WGRAD_SPLITS
+            assert 64 * S <= ROW_PAD                 # operand buffers are padded by ROW_PAD rows (ops_lstm.padded_rows)
             slab = ws("slab", (S * K4 * max(Hd, KX),), torch.float32)
             for dg, off, inp, width, dest in jobs:
                 rows = (Rr - off + 64 * S - 1) // (64 * S) * (64 * S)

@@ -79,7 +79,8 @@ def workspace(key, shape, dtype, device, zero=False):
     return t
 
 
-ROW_PAD = 1024       # row granularity of the weight-gradient GEMM operands (64 rows x up to 16 K-splits)
+WGRAD_SPLITS = 64    # K-slices of the weight-gradient GEMMs (engine._lstm_wgrad)
+ROW_PAD = 64 * WGRAD_SPLITS   # row granularity of their operands: 64-row stages x K-slices; buffers carry this much slack
 
 
 def padded_rows(R, shift=0):
