@@ -151,10 +151,161 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+// LDS-staged variant of gemm_nt_kernel (same arguments and epilogues) for K-slices that are multiples of the 128-byte
+// stage (64 bf16 / 32 f32): 256 threads = 2 x 2 waves, block tile 128 x BN, double-buffered XOR-swizzled LDS with register
+// staging, one barrier per stage.  Operand tiles are read from HBM/L2 once per workgroup instead of once per wave.
+template <typename T, int EPI, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
+  typedef typename Frag<T>::type frag;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  constexpr int KS = BK / 32;
+  constexpr int NJ = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][(128 + BN) * 128];
+  __shared__ double red[2][4];
+  const int ks_ = g.ksplit > 1 ? g.ksplit : 1;
+  const int z = blockIdx.z / ks_, ksl = blockIdx.z % ks_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+  const int srow = tid >> 3, sc = tid & 7;
+  const T* ga = reinterpret_cast<const T*>(g.A) + (size_t)z * g.strideA + (size_t)ksl * g.K + (long)(m0 + srow) * g.lda + sc * EPC;
+  const T* gb = reinterpret_cast<const T*>(g.B) + (size_t)z * g.strideB + (size_t)ksl * g.K + (long)(n0 + srow) * g.ldb + sc * EPC;
+  const int soff = srow * 128 + ((sc ^ (srow & 7)) << 4);
+  const int nstage = g.K / BK;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NGLOAD(k0)                                                            \
+  {                                                                           \
+    ra0 = *reinterpret_cast<const uint4*>(ga + (k0));                         \
+    ra1 = *reinterpret_cast<const uint4*>(ga + 32 * g.lda + (k0));            \
+    ra2 = *reinterpret_cast<const uint4*>(ga + 64 * g.lda + (k0));            \
+    ra3 = *reinterpret_cast<const uint4*>(ga + 96 * g.lda + (k0));            \
+    rb0 = *reinterpret_cast<const uint4*>(gb + (k0));                         \
+    rb1 = *reinterpret_cast<const uint4*>(gb + 32 * g.ldb + (k0));            \
+    if constexpr (NJ == 4) {                                                  \
+      rb2 = *reinterpret_cast<const uint4*>(gb + 64 * g.ldb + (k0));          \
+      rb3 = *reinterpret_cast<const uint4*>(gb + 96 * g.ldb + (k0));          \
+    }                                                                         \
+  }
+#define NLSTORE(buf)                                                          \
+  {                                                                           \
+    *reinterpret_cast<uint4*>(&lds[buf][soff]) = ra0;                         \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 32 * 128]) = ra1;              \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 64 * 128]) = ra2;              \
+    *reinterpret_cast<uint4*>(&lds[buf][soff + 96 * 128]) = ra3;              \
+    *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff]) = rb0;             \
+    *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 32 * 128]) = rb1;  \
+    if constexpr (NJ == 4) {                                                  \
+      *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 64 * 128]) = rb2; \
+      *reinterpret_cast<uint4*>(&lds[buf][128 * 128 + soff + 96 * 128]) = rb3; \
+    }                                                                         \
+  }
+  auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
+    if constexpr (sizeof(T) == 2) {
+      const int c = 4 * ks + q;
+      return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    } else {
+      const int c0 = 2 * q, c1 = 2 * q + 1;
+      const float4 lo = *reinterpret_cast<const float4*>(base + row * 128 + ((c0 ^ (row & 7)) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(base + row * 128 + ((c1 ^ (row & 7)) << 4));
+      frag f;
+      f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+      return f;
+    }
+  };
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  NGLOAD(0)
+  NLSTORE(0)
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstage) NGLOAD((s + 1) * BK)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      frag af[4], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = lfrag(lds[buf], wm * 64 + 16 * i + n, ks);
+        if (g.relu_in) af[i] = relu_frag<T>(af[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = lfrag(lds[buf] + 128 * 128, wn * (BN / 2) + 16 * j + n, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bf[j], acc[i][j]);
+    }
+    if (s + 1 < nstage) NLSTORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef NGLOAD
+#undef NLSTORE
+  // ---- epilogue (identical to gemm_nt_kernel): element (row m0 + wm*64 + 16 i + 4 q + r, col n0 + wn*BN/2 + 16 j + n)
+  T* C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.z * g.strideC;
+  float* Cf = reinterpret_cast<float*>(g.C) + (size_t)blockIdx.z * g.strideC;
+  const float* bias = g.bias ? g.bias + (size_t)z * g.strideBias : nullptr;
+  float slope = 0.f;
+  if (EPI == EPI_PRELU_STATS) slope = g.slope[(size_t)z * g.strideSlope];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + wn * (BN / 2) + 16 * j + n;
+    const bool cvalid = col < g.Nv;
+    const float bv = (bias && cvalid) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + 16 * i + 4 * q + r;
+        const bool valid = cvalid && (row % g.Tp) < g.Tv;
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_PRELU_STATS) v = v > 0.f ? v : slope * v;
+        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI == EPI_RESIDUAL) {
+          const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+          v += to_f32<T>(res[(size_t)row * g.ldres + col]);
+        }
+        if (EPI == EPI_MASK_POS) {
+          const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+          if (!(to_f32<T>(res[(size_t)row * g.ldres + col]) > 0.f)) v = 0.f;
+        }
+        if (!valid) v = 0.f;
+        if (EPI == EPI_PLAIN_F32) {
+          Cf[(size_t)row * g.ldc + col] = v;
+          continue;
+        }
+        const T o = from_f32<T>(v);
+        C[(size_t)row * g.ldc + col] = o;
+        if (EPI == EPI_PRELU_STATS) {
+          const float vo = to_f32<T>(o);
+          s1 += vo;
+          s2 += vo * vo;
+        }
+      }
+  }
+  if (EPI == EPI_PRELU_STATS) {
+    // one sample per 128-row tile (Tp % 128 == 0): one atomic pair per workgroup
+    const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+    if (lane == 0) { red[0][wave] = d1; red[1][wave] = d2; }
+    __syncthreads();
+    if (tid == 0) {
+      double* st = g.stats + (size_t)z * g.strideStats + (size_t)(m0 / g.Tp) * 2;
+      atomicAdd(st, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      atomicAdd(st + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- depthwise stage
 // in  = y1 [B][Tp][ld] (post-PReLU1), GroupNorm-1 statistics (sum, sumsq over the C*Tv valid elements)
 // z   = GN1(y1) on valid frames, 0 outside (conv zero padding)
 // out = PReLU2( bias[c] + sum_k w[c][k] * z[t + (k-1)*dil][c] )   (+ GroupNorm-2 statistics of out)
+constexpr int DW_FRAMES = 32;   // frames per workgroup of the depthwise stage
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                      const double* __restrict__ st1, double* __restrict__ st2,
@@ -162,6 +313,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, T
                                                      const float* __restrict__ wd, const float* __restrict__ bd,
                                                      const float* __restrict__ slope2, int Cc, int ld, int Tp, int Tv, int dil,
                                                      float eps, long strideAct, long strideSt, long strideP) {
+  __shared__ double red[2][4];
   const int z = blockIdx.z, b = blockIdx.y;
   in += (size_t)z * strideAct;
   out += (size_t)z * strideAct;
@@ -174,49 +326,55 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, T
   const double var = st1[b * 2 + 1] / cnt - m * m;
   const float mean = (float)m, rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
   const int cpr = Cc / 8;        // 8-channel chunks per frame; host guarantees cpr <= 256
-  const int rpb = 256 / cpr;     // frames per block
+  const int rpi = 256 / cpr;     // frames per iteration
   const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
-  const int t = blockIdx.x * rpb + tl;
   float s1 = 0.f, s2 = 0.f;
-  if (tl < rpb && t < Tp) {
-    float o[8];
-    if (t < Tv) {
-      float g8[8], be8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        g8[i] = gamma[c8 + i] * rstd;
-        be8[i] = beta[c8 + i] - mean * g8[i];
-        o[i] = bd[c8 + i];
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int ts = t + (k - 1) * dil;
-        if (ts >= 0 && ts < Tv) {
-          const T* p = in + ((size_t)b * Tp + ts) * ld + c8;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += wd[(c8 + i) * 3 + k] * (to_f32<T>(p[i]) * g8[i] + be8[i]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = o[i] > 0.f ? o[i] : a2 * o[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = 0.f;
-    }
-    T* po = out + ((size_t)b * Tp + t) * ld + c8;
+  if (tl < rpi) {
+    float g8[8], be8[8], b8[8], w8[3][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const T ov = from_f32<T>(o[i]);
-      po[i] = ov;
-      const float vf = to_f32<T>(ov);
-      s1 += vf;
-      s2 += vf * vf;
+      g8[i] = gamma[c8 + i] * rstd;
+      be8[i] = beta[c8 + i] - mean * g8[i];
+      b8[i] = bd[c8 + i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w8[k][i] = wd[(c8 + i) * 3 + k];
+    }
+    const int t1 = min((blockIdx.x + 1) * DW_FRAMES, Tp);
+    for (int t = blockIdx.x * DW_FRAMES + tl; t < t1; t += rpi) {
+      float o[8];
+      if (t < Tv) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = b8[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int ts = t + (k - 1) * dil;
+          if (ts >= 0 && ts < Tv) {
+            float v[8];
+            load8<T>(in + ((size_t)b * Tp + ts) * ld + c8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += w8[k][i] * (v[i] * g8[i] + be8[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = o[i] > 0.f ? o[i] : a2 * o[i];
+          const float vf = to_f32<T>(from_f32<T>(o[i]));      // statistics of the STORED (rounded) activations
+          s1 += vf;
+          s2 += vf * vf;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+      }
+      store8<T>(out + ((size_t)b * Tp + t) * ld + c8, o);
     }
   }
   const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(st2 + b * 2, d1);
-    atomicAdd(st2 + b * 2 + 1, d2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d1; red[1][threadIdx.x >> 6] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(st2 + b * 2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(st2 + b * 2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 
@@ -239,13 +397,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in,
   const long total = (long)Tv * cpr;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int t = (int)(e / cpr), c8 = (int)(e % cpr) * 8;
-    const T* p = in + ((size_t)b * Tp + t) * ld + c8;
-    T* po = out + ((size_t)b * Tp + t) * ld + c8;
+    float v[8];
+    load8<T>(in + ((size_t)b * Tp + t) * ld + c8, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float gsc = gamma[c8 + i] * rstd;
-      po[i] = from_f32<T>((to_f32<T>(p[i]) - mean) * gsc + beta[c8 + i]);
-    }
+    for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean) * (gamma[c8 + i] * rstd) + beta[c8 + i];
+    store8<T>(out + ((size_t)b * Tp + t) * ld + c8, v);
   }
 }
 
@@ -282,9 +438,16 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
   if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
              R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit};
-  dim3 grid(R / 128, N / 64, batch * ksplit);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(TT, E) hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), grid, dim3(256), 0, s, g)
+  const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
+  const int lds_path = ((K / ksplit) % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
+  dim3 grid(R / 128, lds_path == 128 ? N / 128 : N / 64, batch * ksplit);
+#define LAUNCH(TT, E)                                                                              \
+  do {                                                                                             \
+    if (lds_path == 128) hipLaunchKernelGGL((gemm_nt_lds_kernel<TT, E, 128>), grid, dim3(256), 0, s, g); \
+    else if (lds_path == 64) hipLaunchKernelGGL((gemm_nt_lds_kernel<TT, E, 64>), grid, dim3(256), 0, s, g); \
+    else hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), grid, dim3(256), 0, s, g);                    \
+  } while (0)
   if (prec == NPPC_PREC_BF16) {
     switch (epi) {
       case EPI_PLAIN: LAUNCH(bf16_t, EPI_PLAIN); break;
@@ -317,8 +480,7 @@ int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, doub
                     const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
                     int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
   if (!in || !out || !st1 || !st2 || Cc % 8 || Cc / 8 > 256) return NPPC_EBADARG;
-  const int cpr = Cc / 8, rpb = 256 / cpr;
-  dim3 grid(ceil_div(Tp, rpb), B, batch);
+  dim3 grid(ceil_div(Tp, DW_FRAMES), B, batch);
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, st1, st2, gamma, beta,

@@ -42,10 +42,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
   if (tl < rpi) {
     for (int t = blockIdx.x * RPB + tl; t < (blockIdx.x + 1) * RPB && t < Tv; t += rpi) {
       const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+      float dv[8], yv8[8];
+      load8<T>(dA + o, dv);
+      load8<T>(y + o, yv8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float d = to_f32<T>(dA[o + i]);
-        const float xh = (to_f32<T>(y[o + i]) - c.mean) * c.rstd;
+        const float d = dv[i];
+        const float xh = (yv8[i] - c.mean) * c.rstd;
         const float dxh = d * gamma[c8 + i];
         s1 += dxh;
         s2 += dxh * xh;
@@ -90,22 +93,28 @@ __global__ __launch_bounds__(256) void gn_prelu_bwd_kernel(const T* __restrict__
   const int cpr = Cc / 8, rpi = 256 / cpr;
   const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
   float da = 0.f;
+  const float inva = 1.f / a;
   if (tl < rpi) {
     for (int t = blockIdx.x * RPB + tl; t < (blockIdx.x + 1) * RPB && t < Tp; t += rpi) {
       const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+      float out[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float out = 0.f;
-        if (t < Tv) {
-          const float yv = to_f32<T>(y[o + i]);
+      for (int i = 0; i < 8; ++i) out[i] = 0.f;
+      if (t < Tv) {
+        float dv[8], yv8[8];
+        load8<T>(dA + o, dv);
+        load8<T>(y + o, yv8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float yv = yv8[i];
           const float xh = (yv - c.mean) * c.rstd;
-          const float dxh = to_f32<T>(dA[o + i]) * gamma[c8 + i];
+          const float dxh = dv[i] * gamma[c8 + i];
           const float dy = c.rstd * (dxh - m1 - xh * m2);
-          if (yv > 0.f) out = dy;
-          else { out = a * dy; da += dy * yv / a; }
+          if (yv > 0.f) out[i] = dy;
+          else { out[i] = a * dy; da += dy * yv * inva; }
         }
-        dpre[o + i] = from_f32<T>(out);
       }
+      store8<T>(dpre + o, out);
     }
   }
   const float ds = wave_sum(da);
@@ -149,26 +158,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
       for (int i = 0; i < 8; ++i) out[i] = 0.f;
       if (t < Tv) {
         float duv[8];
+        load8<T>(du + o, duv);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { duv[i] = to_f32<T>(du[o + i]); ab[i] += duv[i]; }
+        for (int i = 0; i < 8; ++i) ab[i] += duv[i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int ts = t + (k - 1) * dil;       // forward source frame of tap k for output frame t
           if (ts >= 0 && ts < Tv) {
-            const size_t os = ((size_t)b * Tp + ts) * Cc + c8;
+            float yv8[8];
+            load8<T>(y1 + ((size_t)b * Tp + ts) * Cc + c8, yv8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) aw[k][i] += duv[i] * (to_f32<T>(y1[os + i]) * g8[i] + be8[i]);
+            for (int i = 0; i < 8; ++i) aw[k][i] += duv[i] * (yv8[i] * g8[i] + be8[i]);
           }
           const int tu = t - (k - 1) * dil;       // output frame whose tap k reads frame t
           if (tu >= 0 && tu < Tv) {
-            const size_t ou = ((size_t)b * Tp + tu) * Cc + c8;
+            float du8[8];
+            load8<T>(du + ((size_t)b * Tp + tu) * Cc + c8, du8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) out[i] += w8[k][i] * to_f32<T>(du[ou + i]);
+            for (int i = 0; i < 8; ++i) out[i] += w8[k][i] * du8[i];
           }
         }
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dz[o + i] = from_f32<T>(out[i]);
+      store8<T>(dz + o, out);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -26,36 +26,6 @@ __device__ __forceinline__ bool interior(long p, long P, int H, int W) {
   return x >= 1 && x <= (unsigned)W && y >= 1 && y <= (unsigned)H;
 }
 
-// 8 consecutive channels of one pixel as one (bf16) or two (f32) 16-byte accesses; callers guarantee 16-byte alignment
-// (row widths and channel offsets are multiples of 8)
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-  const uint4 u = *reinterpret_cast<const uint4*>(p);
-  const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[2 * i] = __uint_as_float(w[i] << 16);
-    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-  }
-}
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-  uint4 u;
-  u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-  u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-  u.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-  u.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-  *reinterpret_cast<uint4*>(p) = u;
-}
-template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
-  *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<float4*>(p + 4) = float4{v[4], v[5], v[6], v[7]};
-}
-
 // ------------------------------------------------------------------------------------------------ convolution
 struct ConvArgs {
   const void* A; long lda;            // haloed NHWC input, pointer at pixel row 0 (guard rows exist before it)
