@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restri
                                                            TsseW w, TsseG g, const float* __restrict__ ns_in,
                                                            const float* __restrict__ pre, const float* __restrict__ sq,
                                                            const float* __restrict__ h1, const float* __restrict__ sg,
-                                                           const float* __restrict__ dsg, int C, int C2, int T, int la) {
+                                                           const float* __restrict__ dsg, float* __restrict__ da2_ws,
+                                                           float* __restrict__ da1_ws, int C, int C2, int T, int la) {
   __shared__ float da2[TSSE_MAXC];
   __shared__ float da1[TSSE_MAXC / 2];
   __shared__ float dsq[TSSE_MAXC];
@@ -164,25 +165,17 @@ __global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restri
     const float s = sg[(size_t)b * C + c];
     const float d = dsg[(size_t)b * C + c] * s * (1.f - s);
     da2[c] = d;
-    atomicAdd(g.b2 + c, d);
+    da2_ws[(size_t)b * C + c] = d;          // fc2 / fc1 weight gradients: tsse_bwd_outer_kernel (sum over samples)
   }
   __syncthreads();
-  for (int e = tid; e < C * C2; e += 256) {
-    const int c = e / C2, j = e % C2;
-    atomicAdd(g.w2 + e, da2[c] * h1[(size_t)b * C2 + j]);
-  }
   for (int j = tid; j < C2; j += 256) {
     float a = 0.f;
     for (int c = 0; c < C; ++c) a += w.w2[(size_t)c * C2 + j] * da2[c];
     a = h1[(size_t)b * C2 + j] > 0.f ? a : 0.f;
     da1[j] = a;
-    atomicAdd(g.b1 + j, a);
+    da1_ws[(size_t)b * C2 + j] = a;
   }
   __syncthreads();
-  for (int e = tid; e < C2 * C; e += 256) {
-    const int j = e / C, c = e % C;
-    atomicAdd(g.w1 + e, da1[j] * sq[(size_t)b * C + c]);
-  }
   float fsum[3] = {0.f, 0.f, 0.f}, bsum = 0.f;
   for (int c = tid; c < C; c += 256) {
     float a = 0.f;
@@ -219,6 +212,37 @@ __global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restri
   if ((tid & 63) == 0) atomicAdd(g.fcb, v);
 }
 
+// fc weight / bias gradients as batched outer products: one thread per weight element sums over the B samples
+// (one atomic per element per call instead of one per element per sample)
+//   w2[c][j] += sum_b da2[b][c] h1[b][j];  b2[c] += sum_b da2[b][c];  w1[j][c] += sum_b da1[b][j] sq[b][c];  b1[j] += sum_b da1[b][j]
+__global__ __launch_bounds__(256) void tsse_bwd_outer_kernel(const float* __restrict__ da2, const float* __restrict__ da1,
+                                                             const float* __restrict__ h1, const float* __restrict__ sq, TsseG g,
+                                                             int B, int C, int C2) {
+  const int n2 = C * C2;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n2) {
+    const int c = e / C2, j = e % C2;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + c] * h1[(size_t)b * C2 + j];
+    atomicAdd(g.w2 + e, a);
+  } else if (e < 2 * n2) {
+    const int k = e - n2, j = k / C, c = k % C;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + j] * sq[(size_t)b * C + c];
+    atomicAdd(g.w1 + k, a);
+  } else if (e < 2 * n2 + C) {
+    const int c = e - 2 * n2;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + c];
+    atomicAdd(g.b2 + c, a);
+  } else if (e < 2 * n2 + C + C2) {
+    const int j = e - 2 * n2 - C;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + j];
+    atomicAdd(g.b1 + j, a);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -238,8 +262,14 @@ int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsu
     hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
   TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
   TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
-  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(256), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, C, C / 2, T,
-                     look_ahead);
+  // dsg_ws holds B * (2 C + C/2) floats: dsg [B][C] | da2 [B][C] | da1 [B][C/2]
+  float* da2_ws = dsg_ws + (size_t)B * C;
+  float* da1_ws = da2_ws + (size_t)B * C;
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(256), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, da2_ws, da1_ws,
+                     C, C / 2, T, look_ahead);
+  const int C2 = C / 2;
+  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256)), dim3(256), 0, s, da2_ws, da1_ws, h1, sq, g,
+                     B, C, C2);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

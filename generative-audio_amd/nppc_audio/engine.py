@@ -459,7 +459,7 @@ class FSNEngine:
             dXo, dXi = dXi, dXo
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
         sv = d["tsse_saved"]
-        dsg = ws("dsg", (B, F), torch.float32)
+        dsg = ws("dsg", (B * (2 * F + F // 2),), torch.float32)      # dsg | da2 | da1 (csrc/spec.hip: nppc_tsse_bwd)
         maps = d["maps"]
         for z, br in enumerate(BRANCHES):
             att = f"channel_attention{br}."

@@ -48,7 +48,7 @@ int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const 
                   void* stream);
 int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsum, const float* cw0, const float* cw1,
                   const float* cw2, int ks0, int ks1, int ks2, const float* fcw, const float* w1, const float* w2,
-                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws,
+                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws, /* B*(2C + C/2) floats */
                   float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1, float* g_cw2, float* g_cb2, float* g_fcw,
                   float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int C, int T, int look_ahead, int Tp,
                   int ld, int coff, void* stream);
