@@ -109,6 +109,7 @@ SIGS = {
     "nppc_reduce_slabs": [P, I, L, L, P, L, I, I, I, I, I, L, L, I, P],
     "nppc_adam_step": [P, P, P, P, L, D, D, D, D, D, I, D, P],
     "nppc_loss_solve_eps": [P, P, P, P, P, P, P, P, P, P, I, I, D, I, P],
+    "nppc_mix_snr": [P, P, P, F, P, P, I, I, P],
     "nppc_sumsq": [P, L, P, P],
     "nppc_adam_step_clip": [P, P, P, P, L, D, D, D, D, D, I, D, P, D, P],
     "nppc_logmag": [P, P, L, I, L, P, P],

@@ -88,3 +88,18 @@ class SyntheticNoisySpeech(torch.utils.data.Dataset):
     def __getitem__(self, i):
         y, c = synth_clip(self.first + i, self.length)
         return torch.from_numpy(y), torch.from_numpy(c)
+
+
+def mix_with_snr_on_device(clean, noise, snr_db, target_dB_FS=-25.0):
+    """Batched, HBM-resident version of AudioDataset._mix_with_snr (dataset/audio_dataset.py:92-152):
+    clean [B,L], noise [B,L], snr_db [B] (all on the HIP device) -> (noisy [B,L], clean [B,L]).  One kernel launch;
+    lets the training loop synthesise minibatches from resident clip pools instead of a CPU DataLoader."""
+    from . import _hip as H
+    H.require_gpu()
+    clean, noise = clean.contiguous().float(), noise.contiguous().float()
+    snr_db = snr_db.contiguous().float()
+    B, L = clean.shape
+    assert noise.shape == (B, L) and snr_db.shape == (B,)
+    noisy_out, clean_out = torch.empty_like(clean), torch.empty_like(clean)
+    H.call("nppc_mix_snr", clean, noise, snr_db, float(target_dB_FS), noisy_out, clean_out, B, L, H.stream())
+    return noisy_out, clean_out

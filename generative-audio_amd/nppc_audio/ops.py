@@ -94,3 +94,32 @@ def model_outputs_to_waveforms(enhanced_masks, noisy_reals, noisy_imags, orig_le
     """utils.py:37-72: compressed cIRM [B,2,F,T] + noisy STFT [B,1,F,T] -> enhanced waveforms [B, orig_length]."""
     _, ere, eim = cirm_decompress_apply(enhanced_masks, noisy_reals.squeeze(1), noisy_imags.squeeze(1))
     return istft(ere, eim, nfft, hop, orig_length)
+
+
+def crm_directions_to_spectrograms(w_mat, noisy_re, noisy_im):
+    """NPPCAudioValidator._crm_directions_to_spectograms (nppc_audio/validator.py:55-102): every PC direction
+    w_mat[:, k] (compressed cIRM [B,2,F,T]) is decompressed and applied to the noisy STFT with the TRUE complex product
+    (utils.crm_to_spectogram, utils.py:252-256).  w_mat [B,K,2,F,T], noisy_re/im [B,F,T] -> (real, imag) [B,K,F,T]."""
+    B, K, _, F, T = w_mat.shape
+    re = torch.empty(B, K, F, T, dtype=torch.float32, device=w_mat.device)
+    im = torch.empty_like(re)
+    for k in range(K):
+        _, r, i = cirm_decompress_apply(w_mat[:, k], noisy_re, noisy_im)
+        re[:, k], im[:, k] = r, i
+    return re, im
+
+
+def pc_direction_waveforms(pred_crm, w_mat, alphas, noisy_re, noisy_im, length, nfft=512, hop=256):
+    """PC synthesis of the validator (nppc_audio/validator.py:148-302): waveforms of `enhanced + alpha * PC_k` for every
+    direction k and every alpha, all (K * len(alphas) + 1) inverse STFTs as ONE batched overlap-add launch.
+    pred_crm [B,2,F,T] (compressed), w_mat [B,K,2,F,T], alphas: sequence of floats -> (enhanced [B,length],
+    variants [B,K,len(alphas),length])."""
+    B, K = w_mat.shape[:2]
+    _, e_re, e_im = cirm_decompress_apply(pred_crm, noisy_re, noisy_im)
+    d_re, d_im = crm_directions_to_spectrograms(w_mat, noisy_re, noisy_im)
+    a = torch.as_tensor(list(alphas), dtype=torch.float32, device=w_mat.device)
+    A = a.numel()
+    v_re = (e_re[:, None, None] + a[None, None, :, None, None] * d_re[:, :, None]).reshape(B * K * A, *e_re.shape[1:])
+    v_im = (e_im[:, None, None] + a[None, None, :, None, None] * d_im[:, :, None]).reshape(B * K * A, *e_im.shape[1:])
+    waves = istft(torch.cat((e_re, v_re)), torch.cat((e_im, v_im)), nfft, hop, length)
+    return waves[:B], waves[B:].view(B, K, A, length)

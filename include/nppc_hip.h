@@ -160,6 +160,10 @@ int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* gr
 int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                    double wd, int step, double gscale, void* stream);
 
+/* ---- on-device batch synthesis (dataset/audio_dataset.py:92-152: dBFS normalisation, SNR mix, clip guard) ------- */
+int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, float* noisy_out,
+                 float* clean_out, int B, int L, void* stream);
+
 /* clip_grad_norm_(max_norm) + Adam without a host round trip (inpainting/trainer/nppc_trainer.py:149-154):
  * nppc_sumsq accumulates sum(g^2) into a zeroed device double, nppc_adam_step_clip reads it. */
 int nppc_sumsq(const float* g, long n, double* out, void* stream);

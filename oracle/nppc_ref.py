@@ -352,3 +352,19 @@ def adam_step(params, grads, state, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
         bc2 = 1 - b2 ** t
         denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
         p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def mix_with_snr(clean, noise, snr_db, target_dbfs=-25.0):
+    """AudioDataset._normalize_audio + _mix_with_snr (dataset/audio_dataset.py:92-152) for one clip [L] each:
+    clean -> target dBFS, noise scaled to the SNR, clip guard at 0.99.  Returns (noisy, clean)."""
+    rms = clean.pow(2).mean().sqrt()
+    gain = 10 ** ((target_dbfs - 20 * torch.log10(rms + 1e-8)) / 20)
+    clean = clean * gain
+    clean_power, noise_power = clean.pow(2).mean(), noise.pow(2).mean()
+    scale = torch.sqrt(clean_power / (10 ** (snr_db / 10) * noise_power + 1e-8))
+    noisy = clean + noise * scale
+    max_amp = torch.max(torch.abs(noisy))
+    if max_amp > 0.99:
+        f = 0.99 / max_amp
+        noisy, clean = noisy * f, clean * f
+    return noisy, clean

@@ -133,3 +133,43 @@ def test_istft_roundtrip_and_enhanced_waveform(name):
     ref = R.outputs_to_waveforms(mask, n_re, n_im, L, c["nfft"], c["hop"])
     got = ops.model_outputs_to_waveforms(mask.cuda(), n_re[:, None].cuda(), n_im[:, None].cuda(), L, c["nfft"], c["hop"]).cpu()
     assert (got - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_mix_with_snr_on_device():
+    """row f3: on-device batch synthesis vs the reference's AudioDataset._mix_with_snr (golden) incl. the clip guard"""
+    from nppc_audio.data import mix_with_snr_on_device
+    z = np.load(os.path.join(GOLD, "mix_snr.npz"))
+    noisy, clean = mix_with_snr_on_device(torch.from_numpy(z["clean"]).cuda(), torch.from_numpy(z["noise"]).cuda(),
+                                          torch.from_numpy(z["snr"]).cuda())
+    assert np.abs(noisy.cpu().numpy() - z["noisy_out"]).max() < 2e-6
+    assert np.abs(clean.cpu().numpy() - z["clean_out"]).max() < 2e-6
+    assert float(noisy[4].abs().max()) <= 0.99 + 1e-6
+
+
+def test_pc_direction_spectrograms_and_waveforms():
+    """row f1: validator PC synthesis (decompress + true complex product per direction, batched iSTFT of
+    enhanced + alpha * PC) vs the oracle's restatement of utils.crm_to_spectogram / torch.istft"""
+    from nppc_audio import ops
+    z, meta = load("g0_tiny")
+    c = meta["config"]
+    n_re, n_im = torch.from_numpy(z["noisy_real"][:, 0]), torch.from_numpy(z["noisy_imag"][:, 0])
+    pred = torch.from_numpy(z["pred_crm_full"])
+    B, F, T = n_re.shape
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(B, 3, 2, F, T, generator=g) * 2.0
+    L = z["noisy"].shape[1]
+    re, im = ops.crm_directions_to_spectrograms(w.cuda(), n_re.cuda(), n_im.cuda())
+    alphas = [-3.0, -0.6, 1.8]
+    enh, var = ops.pc_direction_waveforms(pred.cuda(), w.cuda(), alphas, n_re.cuda(), n_im.cuda(), L, c["nfft"], c["hop"])
+    d_pred = R.decompress_mask(pred)
+    e_re = d_pred[:, 0] * n_re - d_pred[:, 1] * n_im
+    e_im = d_pred[:, 1] * n_re + d_pred[:, 0] * n_im
+    assert rel(enh.cpu().numpy(), R.istft_wave(e_re, e_im, c["nfft"], c["hop"], L).numpy()) < 2e-5
+    for k in range(3):
+        d = R.decompress_mask(w[:, k])
+        r_ref = d[:, 0] * n_re - d[:, 1] * n_im
+        i_ref = d[:, 1] * n_re + d[:, 0] * n_im
+        assert rel(re[:, k].cpu().numpy(), r_ref.numpy()) < 2e-5 and rel(im[:, k].cpu().numpy(), i_ref.numpy()) < 2e-5
+        for ai, a in enumerate(alphas):
+            ref = R.istft_wave(e_re + a * r_ref, e_im + a * i_ref, c["nfft"], c["hop"], L).numpy()
+            assert rel(var[:, k, ai].cpu().numpy(), ref) < 5e-5

@@ -179,3 +179,13 @@ def test_explicit_lstm_recurrence_matches_fused():
     a = R.lstm2(x, P, "sb_model.sequence_model")
     b = R.lstm2_steps(x, P, "sb_model.sequence_model")
     assert (a - b).abs().max() < 1e-6
+
+
+def test_mix_with_snr_golden(golden_dir):
+    """batch synthesis (row f3): oracle vs the reference's AudioDataset._mix_with_snr outputs"""
+    z = np.load(os.path.join(golden_dir, "mix_snr.npz"))
+    assert np.abs(z["noisy_out"][4]).max() > 0.98          # the clip-guard case is in the fixture
+    for i in range(z["clean"].shape[0]):
+        n, c = R.mix_with_snr(torch.from_numpy(z["clean"][i]), torch.from_numpy(z["noise"][i]), float(z["snr"][i]))
+        assert np.abs(n.numpy() - z["noisy_out"][i]).max() < 1e-6
+        assert np.abs(c.numpy() - z["clean_out"][i]).max() < 1e-6

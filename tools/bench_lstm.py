@@ -35,3 +35,24 @@ for prec, name in precs:
             flops = N * Tn * 2 * 1536 * (34 + 384 + 768)
             print(f"{name} N={N} train={train} mtile={mt}: {dt*1e3:.2f} ms  {flops/dt/1e12:.1f} TFLOP/s "
                   f"finite={bool(torch.isfinite(out['h2'].float()).all())} timeouts={ops_lstm.coop_timeouts()}", flush=True)
+
+if "--bwd" in sys.argv:
+    from nppc_audio.ops_lstm import PackedLSTMBwd, lstm2_backward
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*ws)
+    pb = PackedLSTMBwd(I, Hd, 0, dev).pack(ws[0], ws[1], ws[4], ws[5])
+    N = 4096
+    x = torch.randn(Tn, N, pk.kx, device=dev).to(torch.bfloat16)
+    x[:, :, I:] = 0
+    saved = lstm2_forward(x, pk, True, None)
+    dh2 = (torch.randn(Tn, N, Hd, device=dev) * 0.01).to(torch.bfloat16)
+    for _ in range(2):
+        out = lstm2_backward(saved, dh2, pb, pk.kx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = lstm2_backward(saved, dh2, pb, pk.kx)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    flops = N * Tn * 2 * 1536 * (34 + 384 + 768)
+    print(f"bf16 coop bwd N={N}: {dt*1e3:.2f} ms  {flops/dt/1e12:.1f} TFLOP/s finite={bool(torch.isfinite(out[0].float()).all())} "
+          f"dx_sum={float(out[0].float().abs().sum()):.6e} timeouts={ops_lstm.coop_timeouts()}", flush=True)
