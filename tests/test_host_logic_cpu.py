@@ -134,3 +134,44 @@ def test_synthetic_dataset_matches_oracle_recipe():
     for i in range(3):
         y, c = ds[i]
         assert np.array_equal(y.numpy(), noisy[i]) and np.array_equal(c.numpy(), clean[i])
+
+
+def test_checkpoint_wire_format_round_trip(tmp_path):
+    """row f2: save_checkpoint writes {model_state_dict, optimizer_state_dict, step} with the reference's tensor names
+    (trainer.py:319-335) and it loads back strictly; the restorer file format {"model": sd} is read by preload_model."""
+    import numpy as np
+    import torch
+    from oracle import weights as W
+    from nppc_audio.data import SyntheticNoisySpeech
+    from nppc_audio.fullsubnet import FullSubNet_Plus, FullSubNetPlusConfig
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    tiny = dict(num_freqs=33, sb_num_neighbors=3, sb_model_hidden_size=16)
+    ck = str(tmp_path / "restorer.tar")
+    torch.save({"model": FullSubNet_Plus(FullSubNetPlusConfig(**tiny)).state_dict()}, ck)
+    cfg = NPPCAudioTrainerConfig(
+        nppc_model_configuration=dict(
+            pretrained_restoration_model_configuration=tiny, pretrained_restoration_model_path=ck,
+            audio_pc_wrapper_configuration=dict(multi_direction_configuration=dict(tiny, n_directions=3)),
+            stft_configuration=dict(nfft=64, hop_length=32, win_length=64), device="cpu"),
+        data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+        data_loader_configuration=dict(batch_size=2, num_workers=0, pin_memory=False, shuffle=False),
+        optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4)), device="cpu")
+    tr = NPPCAudioTrainer(cfg, dataset=SyntheticNoisySpeech(2, 1024))
+    tr.step = 7
+    path = str(tmp_path / "ck" / "checkpoint.pt")
+    tr.save_checkpoint(path)
+    ckpt = torch.load(path, map_location="cpu")
+    assert set(ckpt) == {"model_state_dict", "optimizer_state_dict", "step"} and ckpt["step"] == 7
+    spec = W.nppc_spec(3, num_freqs=33, sb_neighbors=3, sb_hidden=16)
+    assert list(ckpt["model_state_dict"]) == list(spec)
+    assert all(tuple(ckpt["model_state_dict"][k].shape) == tuple(spec[k]) for k in spec)
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4).state_dict()
+    got_opt = ckpt["optimizer_state_dict"]
+    assert set(got_opt) == set(ref_opt) and len(got_opt["param_groups"]) == 1
+    for k in ("lr", "betas", "eps", "weight_decay"):
+        assert got_opt["param_groups"][0][k] == ref_opt["param_groups"][0][k], k
+    tr2 = NPPCAudioTrainer(cfg, dataset=SyntheticNoisySpeech(2, 1024))
+    tr2.nppc_model.load_state_dict(ckpt["model_state_dict"], strict=True)
+    tr2.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    for (n1, p1), (n2, p2) in zip(tr.nppc_model.state_dict().items(), tr2.nppc_model.state_dict().items()):
+        assert n1 == n2 and np.array_equal(p1.numpy(), p2.numpy())
