@@ -109,6 +109,12 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
   *reinterpret_cast<float4*>(p + 4) = float4{v[4], v[5], v[6], v[7]};
 }
 
+// Non-temporal 16-byte accesses for data that is touched ONCE per launch (saved LSTM state, gate gradients): keeps it
+// from evicting the re-read weight fragments out of the 4 MB per-XCD L2 (MI355X_MICROARCH.md, nt-weights row: nt on
+// once-read streams, never on slices every CU re-reads).
+__device__ __forceinline__ u32x4 ld_nt16(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+__device__ __forceinline__ void st_nt16(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+
 // v_exp_f32 / v_rcp_f32 based (1 ulp each): absolute error ~1e-7, saturate cleanly for |x| large
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }

@@ -108,6 +108,21 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
   *reinterpret_cast<uint2*>(p) = v;
 }
 
+// saved state / outputs are written once and read by a LATER kernel: non-temporal stores keep them out of the L2 that
+// holds the weight fragments every step re-reads
+template <typename T> __device__ __forceinline__ void store4_nt(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4_nt<float>(float* p, float a, float b, float c, float d) {
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, reinterpret_cast<f32x4*>(p));
+}
+template <> __device__ __forceinline__ void store4_nt<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  u32x2 v;
+  v[0] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  v[1] = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+}
+template <typename T> __device__ __forceinline__ void store1_nt(T* p, float v) { __builtin_nontemporal_store(from_f32<T>(v), p); }
+
 // LDS row (elements): [X0 (KX) | X1 (KX) | H1 (H) | H2 (H)] + pad.  H = 384 = 12 k-steps.
 template <typename T, int G, int MT, int KX, bool TRAIN>
 __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(CoopArgs a) {
@@ -265,7 +280,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         xrg[u] = make_uint4(0, 0, 0, 0);
         if (ch < nchunk) {
           const int r = ch / cpr, cc = ch % cpr;
-          if (row0 + r < N) xrg[u] = *reinterpret_cast<const uint4*>(xg + ((size_t)(t + 1) * N + row0 + r) * KX + cc * VEC);
+          if (row0 + r < N) {
+            const u32x4 xv = ld_nt16(xg + ((size_t)(t + 1) * N + row0 + r) * KX + cc * VEC);
+            xrg[u] = make_uint4(xv[0], xv[1], xv[2], xv[3]);
+          }
         }
       }
     }
@@ -308,9 +326,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           hn1[mt][j] = ov * tanh_f(cn);
           if (TRAIN && rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
-            c1o[e] = from_f32<T>(cn);
-            store4<T>(g1o + e * 4, iv1[mt][j], gv1[mt][j], fv, ov);
-            h1o[e] = from_f32<T>(hn1[mt][j]);
+            store1_nt<T>(c1o + e, cn);
+            store4_nt<T>(g1o + e * 4, iv1[mt][j], gv1[mt][j], fv, ov);
+            store1_nt<T>(h1o + e, hn1[mt][j]);
           }
         }
     }
@@ -386,10 +404,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           hn2[mt][j] = ov * tanh_f(cn);
           if (rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
-            h2o[e] = from_f32<T>(hn2[mt][j]);
+            store1_nt<T>(h2o + e, hn2[mt][j]);
             if (TRAIN) {
-              c2o[e] = from_f32<T>(cn);
-              store4<T>(g2o + e * 4, iv2[mt][j], gv2[mt][j], fv, ov);
+              store1_nt<T>(c2o + e, cn);
+              store4_nt<T>(g2o + e * 4, iv2[mt][j], gv2[mt][j], fv, ov);
             }
           }
         }
@@ -508,11 +526,12 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
     if (!prow_ok || t < 0) return;
     const size_t e = ((size_t)t * N + row0 + prow) * H + u0;
 #pragma unroll
-    for (int i = 0; i < UPT * 4 * 2 / 16; ++i) reinterpret_cast<uint4*>(sv.g)[i] = reinterpret_cast<const uint4*>(gs + e * 4)[i];
-    *reinterpret_cast<uint4*>(sv.ct) = *reinterpret_cast<const uint4*>(cs + e);
-    if (t > 0) *reinterpret_cast<uint4*>(sv.cp) = *reinterpret_cast<const uint4*>(cs + e - (size_t)N * H);
-    if (dh_ext) *reinterpret_cast<uint4*>(sv.dh) = *reinterpret_cast<const uint4*>(dh_ext + e);
+    for (int i = 0; i < UPT * 4 * 2 / 16; ++i) reinterpret_cast<u32x4*>(sv.g)[i] = ld_nt16(gs + e * 4 + 8 * i);
+    *reinterpret_cast<u32x4*>(sv.ct) = ld_nt16(cs + e);
+    if (t > 0) *reinterpret_cast<u32x4*>(sv.cp) = ld_nt16(cs + e - (size_t)N * H);
+    if (dh_ext) *reinterpret_cast<u32x4*>(sv.dh) = ld_nt16(dh_ext + e);
   };
+  // cell backward of this thread's (row, 8 units) -> gate gradients (bf16, k = unit*4 + gate) into the LDS A operand
   auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float (&dc)[UPT], int t) {
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
@@ -532,10 +551,12 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
         df = dct * cp * fv * (1.f - fv);
         dc[i] = dct * fv;
       }
-      store4<T>(Abuf + prow * RSA + (u0 + i) * 4, di, dg, df, dO);
+      store4<T>(Abuf + prow * RSA + (u0 + i) * 4, di, dg, df, dO);   // 8-byte LDS stores (16-byte ones measured slower)
     }
   };
-  // own half of the dgates tile: columns [cu*768, +768) of Abuf -> partner (write-through, drained, flagged)
+  // own half of the dgates tile: columns [cu*768, +768) of Abuf -> partner (write-through, drained, flagged).  Read back
+  // from LDS so that consecutive lanes store consecutive 16-byte chunks: storing each thread's own 64 bytes straight from
+  // its registers was measured 34 % SLOWER for the whole kernel (partial-line write-through transactions).
   auto publish = [&](int layer, int ep) {
     const int base = ((layer * 2 + (ep & 1)) * 2 + cu) * XSL * 2;
     for (int ch = tid; ch < HALF_CH; ch += NT) {
@@ -548,13 +569,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
     if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // ... and -> dg (row-major [t*N + row][4H], own 768 columns) for the weight-gradient GEMMs.  Issued AFTER the hand-off
-  // so that the publish drain does not wait for these stores; nothing in the kernel reads them.
+  // so that the publish drain does not wait for these stores; nothing in the kernel reads them (non-temporal).
   auto store_T = [&](T* dg, int t) {
     for (int ch = tid; ch < HALF_CH; ch += NT) {
       const int r = ch / (CB_KC / 8), cc = ch % (CB_KC / 8);
       if (row0 + r < N)
-        *reinterpret_cast<u32x4*>(dg + ((size_t)t * N + row0 + r) * CB_K4 + cu * CB_KC + cc * 8) =
-            *reinterpret_cast<const u32x4*>(Abuf + r * RSA + cu * CB_KC + cc * 8);
+        st_nt16(dg + ((size_t)t * N + row0 + r) * CB_K4 + cu * CB_KC + cc * 8,
+                *reinterpret_cast<const u32x4*>(Abuf + r * RSA + cu * CB_KC + cc * 8));
     }
   };
   auto consume = [&](int layer, int ep) {
@@ -635,7 +656,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
           const int r = 16 * mt + 4 * q + j;
           dh1buf[r * HC + 16 * wave + n] = acc[0][mt][j];                    // d h1_{t-1} (recurrent)
           if (has_dx && row0 + r < N)
-            dx[((size_t)t * N + row0 + r) * KX + cu * 32 + 16 * wave + n] = f2bf(acc[1][mt][j]);
+            store1_nt<T>(dx + ((size_t)t * N + row0 + r) * KX + cu * 32 + 16 * wave + n, acc[1][mt][j]);
         }
     }
     __syncthreads();
