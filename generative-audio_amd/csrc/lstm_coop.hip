@@ -18,6 +18,22 @@ namespace {
 
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
+// Workgroup -> (cluster, cu).  Workgroups are dealt round-robin to the 8 XCDs in linear id order, each XCD with its own
+// 4 MB L2.  For CU pairs (G = 2, grid a multiple of 8) every cu-0 workgroup is placed on XCDs 0-3 and every cu-1
+// workgroup on XCDs 4-7: an XCD then caches only ONE half of the weights (1.85 MB instead of 3.7 MB), so the fragments
+// that all its CUs re-read every step stay L2-resident.  Workgroups past the last cluster (grid rounding) exit at once.
+__device__ __forceinline__ void coop_ids(int G, int& cluster, int& cu) {
+  const int b = blockIdx.x;
+  if (G == 2 && (gridDim.x & 7) == 0) {
+    const int x = b & 7;
+    cu = x >> 2;
+    cluster = (b >> 3) * 4 + (x & 3);
+  } else {
+    cluster = b / G;
+    cu = b % G;
+  }
+}
+
 struct CoopArgs {
   const void* x;      // [Tn][N][KX]
   const void* wp1;    // packed like lstm.hip (pair-major, 8 "waves" x 48 units): re-indexed here per 16-unit block
@@ -140,7 +156,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cluster = blockIdx.x / G, cu = blockIdx.x % G;
+  int cluster, cu;
+  coop_ids(G, cluster, cu);
+  if (cluster >= a.clusters) return;
   const int ublk = cu * NW + wave;                                // global 16-unit block of this wave
   const int unit_n = ublk * 16 + n;
   const long row0 = (long)cluster * MC;
@@ -491,7 +509,10 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cluster = blockIdx.x / CB_G, cu = blockIdx.x % CB_G, pcu = 1 - cu;
+  int cluster, cu;
+  coop_ids(CB_G, cluster, cu);
+  if (cluster >= a.clusters) return;
+  const int pcu = 1 - cu;
   const long row0 = (long)cluster * MC;
   const long N = a.N;
   for (int i = tid; i < 2 * MC * HC; i += NT) dh1buf[i] = 0.f;
@@ -710,7 +731,9 @@ static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
       hipSuccess)
     return NPPC_ELAUNCH;
   if (hipMemsetAsync(a.flags, 0, ((size_t)a.clusters * 2 * G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
-  hipLaunchKernelGGL(k, dim3(a.clusters * G), dim3((H / G / 16) * 64), smem, s, a);
+  // G = 2: grid rounded up to a multiple of 8 for the XCD-aware placement (coop_ids); spare workgroups exit at once
+  const int grid = G == 2 ? round_up(a.clusters * G, 8) : a.clusters * G;
+  hipLaunchKernelGGL(k, dim3(grid), dim3((H / G / 16) * 64), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
@@ -790,7 +813,7 @@ int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const vo
                           (int)smem) != hipSuccess)
     return NPPC_ELAUNCH;
   if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
-  hipLaunchKernelGGL(lstm2_coop_bwd_kernel, dim3(clusters * CB_G), dim3(CB_NT), smem, s, a);
+  hipLaunchKernelGGL(lstm2_coop_bwd_kernel, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -107,6 +107,7 @@ class FSNEngine:
         self.I = 2 * sb_neighbors + 1 + 3
         self.sP = flat.branch_stride()
         self.packed_version = None
+        self._side = None                     # side stream for the LSTM weight-gradient GEMMs (backward)
         self.bufs = {}
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
         self.KX = self.lstm.kx
@@ -391,7 +392,14 @@ class FSNEngine:
         # ---- 3. LSTM weight gradients: dW[k][c] = sum_rows dgates[row][k] * input[row][c], rows = (t, sequence).
         # Row-major operands straight from the recurrent kernels; h_{t-1} is the same buffer one time block (Nseq rows)
         # earlier; the staged input carries a ones column (index I), so its product column is the bias gradient.
-        self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq)
+        # They only feed the flat gradient, so they run on a side stream beside the full-band backward chain below
+        # (dozens of small kernels that leave most CUs idle); joined at the end of backward.
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq)
         # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
         dpre_fb = ws("dpre_fb", (3, B, Tp, ldF), zero=True)
         Dsb = ws("Dsb", (B,), torch.float64)
@@ -475,4 +483,5 @@ class FSNEngine:
                        self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
                        self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"),
                        self.g(att + "fc2.bias"), B, F, T, self.la, Tp, ldC, m * F, s)
+        torch.cuda.current_stream().wait_stream(self._side)       # join the LSTM weight-gradient stream
         return G
