@@ -717,6 +717,372 @@ __global__ void lstm_coop_pack_bwd_kernel(const float* __restrict__ w_ih, const 
   }
 }
 
+// =====================================================================================================
+// Cooperative backward, K-split variant.  Same CU pair / 32-sequence tile / unit ownership as above, but the two
+// backward GEMMs are split along K (the gate columns) instead of along their outputs:
+//   CU `cu` multiplies ITS OWN dgates half [32][768] (already in its LDS: no hand-off before the GEMM) with the
+//   weight rows of its own units and ALL output columns -> a partial sum of every output,
+//   keeps the partials of the outputs it owns and sends the rest to the partner as bf16 (reduce-scatter).
+// Per step a CU ships 32 x (384 + 224) bf16 = 38 KB instead of 2 x 48 KB of gate gradients, the GEMM never waits for
+// the partner, and the LDS A operand shrinks to the own half (50 KB).  The weight bytes streamed per CU are unchanged.
+//   layer 2 outputs (48 column tiles of 16): [d h1_t (384) | d h2_{t-1} (384)]
+//   layer 1 outputs (28 column tiles):       [d h1_{t-1} (384) | d x_t (64)]
+// Column tile tau is computed by wave tau % 12 in slot tau / 12; a tile belongs to the CU that owns its units
+// (h tiles: tau % 24 / 12, x tiles: columns 0-31 -> cu 0, 32-63 -> cu 1).
+struct CoopBwd2Args {
+  const void* g1; const void* g2; const void* c1; const void* c2; const void* dh2;
+  const void* wb1; const void* wb2;   // packed by lstm_coop_pack_bwd2_kernel
+  void* dx; void* dg1; void* dg2;     // dg [Tn][N][4H]
+  void* xch;                          // [clusters][2 layers][2 parities][2 CUs][32][384] bf16 partial sums
+  unsigned* flags;                    // [clusters][2 layers][2] epochs + timeout word
+  long N; int Tn; int clusters;
+};
+
+constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over the own gate columns
+constexpr int C2_SLOTS = 4;                                 // column tiles per wave (layer 2: 4, layer 1: 2 or 3)
+constexpr int C2_XW = 2 * CB_HC;                            // 384 partial columns exchanged per row (layer 1 uses 224)
+
+// B fragment (cu, wave, kk, slot): [cu][wave][kk][slot][lane][8]
+__device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) {
+  return ((((cu * CB_NW + wave) * C2_NKK + kk) * C2_SLOTS + slot) * 512) * 2;
+}
+
+// one pass over the own K (24 k-steps) for up to two of this wave's column tiles (slot ids s0, s1)
+// `side(i)` is called once per ring round (i = 0 .. 24/DEPTH - 1): background work spread over the GEMM
+template <int NS, typename Side>
+__device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, __amdgpu_buffer_rsrc_t wr, int cu, int wave,
+                                        int lane, int RS, int s0, int s1, Side&& side) {
+  constexpr int DEPTH = 4;
+  bf16x8 b[DEPTH][2];
+  auto loadb = [&](bf16x8(&bb)[2], int kk) {
+    bb[0] = BFrag<bf16_t>::load(wr, lane, c2_frag_boff(cu, wave, kk, s0));
+    if (NS == 2) bb[1] = BFrag<bf16_t>::load(wr, lane, c2_frag_boff(cu, wave, kk, s1));
+  };
+  auto compute = [&](const bf16x8(&bb)[2], int kk) {
+    bf16x8 af[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RS + 32 * kk);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[s][mt] = mma16(af[mt], bb[s], acc[s][mt]);
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) loadb(b[d], d);
+#pragma unroll 1
+  for (int kk = 0; kk < C2_NKK; kk += DEPTH) {
+    side(kk / DEPTH);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int kl = kk + d + DEPTH - 1;
+      if (kl < C2_NKK) loadb(b[(d + DEPTH - 1) % DEPTH], kl);
+      compute(b[d], kk + d);
+    }
+  }
+  static_assert(C2_NKK % DEPTH == 0, "ring depth divides the k-steps");
+}
+
+// diagnostic phase timers (tools/diag/stamp_bwd2.py builds with -DC2_STAMP): thread 0 of workgroup 0 accumulates
+// s_memtime deltas per phase and leaves them behind the flag words
+#ifdef C2_STAMP
+#define C2_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define C2T(i) if (blockIdx.x == 0 && tid == 0) { const unsigned long long nw = __builtin_readcyclecounter(); st_acc[i] += nw - st_last; st_last = nw; }
+#define C2_STAMP_FINI if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 12; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * 2 * CB_G + 4))[i] = st_acc[i]; }
+#else
+#define C2T(i)
+#endif
+
+__global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
+  typedef bf16_t T;
+  constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
+  constexpr int RSA = CB_KC + 8;                            // A tile row stride (elements): own gate columns only
+  constexpr int TPR = NT / MC, UPT = HC / TPR;              // 24 threads per row, 8 units per thread
+  constexpr int XCH_CH = MC * C2_XW * 2 / 16;               // 16-byte chunks of one partial slab (1536)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Abuf = reinterpret_cast<T*>(smem_raw);                                          // [32][RSA]   own dgates
+  float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)MC * RSA * sizeof(T));  // [32][HC]    d h1 (own units)
+  float* dhrec2 = dh1buf + MC * HC;                                                   // [32][HC]    d h2 recurrent
+  float* dxbuf = dhrec2 + MC * HC;                                                    // [32][32]    own d x partial
+  T* stage = reinterpret_cast<T*>(dxbuf + MC * 32);                                   // [32][384]   partials for the partner
+
+#ifdef C2_STAMP
+  C2_STAMP_INIT
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4, n_ = n, q_ = q;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int cluster, cu;
+  coop_ids(CB_G, cluster, cu);
+  if (cluster >= a.clusters) return;
+  const int pcu = 1 - cu;
+  const long row0 = (long)cluster * MC;
+  const long N = a.N;
+  for (int i = tid; i < 2 * MC * HC + MC * 32; i += NT) dh1buf[i] = 0.f;
+  for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
+
+  const int prow = tid / TPR;
+  const bool prow_ok = row0 + prow < N;
+  float dc1[UPT], dc2[UPT];
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) dc1[i] = dc2[i] = 0.f;
+
+  const T* g1 = reinterpret_cast<const T*>(a.g1);
+  const T* g2 = reinterpret_cast<const T*>(a.g2);
+  const T* c1 = reinterpret_cast<const T*>(a.c1);
+  const T* c2 = reinterpret_cast<const T*>(a.c2);
+  const T* dh2 = reinterpret_cast<const T*>(a.dh2);
+  T* dx = reinterpret_cast<T*>(a.dx);
+  T* dg1T = reinterpret_cast<T*>(a.dg1);
+  T* dg2T = reinterpret_cast<T*>(a.dg2);
+  constexpr unsigned WB = CB_G * CB_NW * C2_NKK * C2_SLOTS * 512 * 2;
+  const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(a.wb1, WB), wr2 = make_rsrc(a.wb2, WB);
+  constexpr int XSL = MC * C2_XW;                                                   // elements of one partial slab
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const T*>(a.xch) + (size_t)cluster * 2 * 2 * 2 * XSL,
+                                              (unsigned)(2 * 2 * 2 * XSL * sizeof(T)));
+  gu32* flags = (gu32*)(a.flags + (size_t)cluster * 2 * CB_G);
+  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * 2 * CB_G);
+  const T* a_lane = Abuf + n * RSA + 8 * q;
+  __syncthreads();
+
+  // Thread -> data: 24 threads per row; thread (prow, tc) owns the four 16-byte chunks c_j = tc + 24 j (j = 0..3) of the
+  // row's own-unit gate block, i.e. units 2 c_j, 2 c_j + 1.  Consecutive lanes then touch consecutive 16-byte chunks in
+  // LDS and in HBM, so the gate gradients go to dg straight from the registers of the cell backward (coalesced,
+  // non-temporal) and their write acknowledgements return while the rest of the cell phase computes -- issued around
+  // the GEMMs they stalled the weight-fragment ring, because stores and loads share the in-order vmcnt counter.
+  const int tc_ = tid % TPR;
+  struct Saved { u32x4 g[4]; unsigned ct[4], cp[4], dh[4]; };     // packed bf16 pairs: 28 VGPRs
+  auto ld_nt4 = [](const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); };
+  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t) {
+    if (!prow_ok || t < 0) return;
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));          // keep the per-chunk addresses out of the loop-invariant (spilled) set
+    const size_t e = ((size_t)t * N + row0 + prow) * H + cu * HC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tc + TPR * j;
+      sv.g[j] = ld_nt16(gs + e * 4 + 8 * c);
+      sv.ct[j] = ld_nt4(cs + e + 2 * c);
+      if (t > 0) sv.cp[j] = ld_nt4(cs + e - (size_t)N * H + 2 * c);
+      if (dh_ext) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
+    }
+  };
+  auto lo16 = [](unsigned w) { return __uint_as_float(w << 16); };
+  auto hi16 = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
+  // cell backward -> gate gradients (bf16, local k = unit*4 + gate): LDS A operand + dg [t*N + row][4H] (own 768 columns)
+  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float (&dc)[UPT], int t, T* dg) {
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tc + TPR * j;
+      u32x4 out = {0u, 0u, 0u, 0u};
+      if (prow_ok) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const unsigned w0 = sv.g[j][2 * e], w1 = sv.g[j][2 * e + 1];   // (i, g), (f, o) of unit 2c + e
+          const float iv = lo16(w0), gv = hi16(w0), fv = lo16(w1), ov = hi16(w1);
+          const float ct = e ? hi16(sv.ct[j]) : lo16(sv.ct[j]);
+          const float cp = t > 0 ? (e ? hi16(sv.cp[j]) : lo16(sv.cp[j])) : 0.f;
+          float dh = dh_lds[prow * HC + 2 * c + e];
+          if (has_ext) dh += e ? hi16(sv.dh[j]) : lo16(sv.dh[j]);
+          const float tch = tanh_f(ct);
+          const float dct = dh * ov * (1.f - tch * tch) + dc[2 * j + e];
+          const float dO = dh * tch * ov * (1.f - ov);
+          const float di = dct * gv * iv * (1.f - iv);
+          const float dgg = dct * iv * (1.f - gv * gv);
+          const float df = dct * cp * fv * (1.f - fv);
+          dc[2 * j + e] = dct * fv;
+          out[2 * e] = (uint32_t)f2bf(di) | ((uint32_t)f2bf(dgg) << 16);
+          out[2 * e + 1] = (uint32_t)f2bf(df) | ((uint32_t)f2bf(dO) << 16);
+        }
+#ifndef C2_NO_DG
+        st_nt16(dg + ((size_t)t * N + row0 + prow) * CB_K4 + cu * CB_KC + 8 * c, out);
+#endif
+      }
+      *reinterpret_cast<u32x4*>(Abuf + prow * RSA + 8 * c) = out;
+    }
+  };
+  // partials for the partner: stage [32][384] -> exchange slab (write-through, coalesced), drained, flagged
+  auto publish = [&](int layer, int ep) {
+    const int base = ((layer * 2 + (ep & 1)) * 2 + cu) * XSL * 2;
+    for (int ch = tid; ch < XCH_CH; ch += NT)
+      store_sc1_b128(xr, base + ch * 16, *reinterpret_cast<const u32x4*>(stage + ch * 8));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // partner's partials of MY outputs: added into the fp32 LDS buffers (layer 2: d h1 | d h2 rec; layer 1: d h1 rec | d x)
+  auto consume = [&](int layer, int ep) {
+    if (wave == 0) {
+      if (lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > SPIN_LIMIT) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    const int base = ((layer * 2 + (ep & 1)) * 2 + pcu) * XSL * 2;
+    const int ncol = layer == 1 ? C2_XW : HC + 32;                      // valid partial columns per row
+    for (int ch = tid; ch < XCH_CH; ch += NT) {
+      const int r = ch / (C2_XW / 8), c0 = (ch % (C2_XW / 8)) * 8;
+      if (c0 >= ncol) continue;
+      const u32x4 v = load_sc1_b128(xr, base + ch * 16);
+      float* dst = c0 < HC ? dh1buf + r * HC + c0 : (layer == 1 ? dhrec2 + r * HC + (c0 - HC) : dxbuf + r * 32 + (c0 - HC));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dst[2 * i] += __uint_as_float(v[i] << 16);
+        dst[2 * i + 1] += __uint_as_float(v[i] & 0xffff0000u);
+      }
+    }
+  };
+  // one 16-column tile of accumulators (slot sl of this wave: column tile tau = wave + 12*sl) -> the fp32 LDS buffer of
+  // the outputs this CU owns, or (bf16) the staging slab of partials for the partner
+  auto scatter = [&](const f32x4 (&acc)[2], int sl, int layer) {
+    // the lane-dependent part of every address below is re-derived from an opaque copy of (n, q) on each call: as loop
+    // invariants the compiler hoisted ~50 precomputed addresses out of the time loop and spilled them to scratch, whose
+    // reloads (global-memory latency) made this epilogue cost more than the GEMM
+    int n = n_, q = q_;
+    asm volatile("" : "+v"(n), "+v"(q));
+    const int tau = wave + CB_NW * sl;
+    int owner, col, ld_own = HC;
+    float* own_dst;
+    bool overwrite = true;
+    if (layer == 1) {          // LSTM layer 2: tiles 0-23 d h1 (accumulate onto the recurrent part), 24-47 d h2 rec
+      const int blk = tau / 24, tt = tau % 24;
+      owner = tt / 12;
+      col = blk * HC + (tt % 12) * 16;
+      own_dst = (blk == 0 ? dh1buf : dhrec2) + (tt % 12) * 16;
+      overwrite = blk == 1;
+    } else if (tau < 24) {     // LSTM layer 1: tiles 0-23 d h1 rec
+      owner = tau / 12;
+      col = (tau % 12) * 16;
+      own_dst = dh1buf + (tau % 12) * 16;
+    } else {                   // LSTM layer 1: tiles 24-27 d x (columns 0-31 -> cu 0, 32-63 -> cu 1)
+      owner = (tau - 24) / 2;
+      col = HC + ((tau - 24) % 2) * 16;
+      own_dst = dxbuf + ((tau - 24) % 2) * 16;
+      ld_own = 32;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 16 * mt + 4 * q + j;
+        const float v = acc[mt][j];
+        if (owner == cu) {
+          float* d = own_dst + r * ld_own + n;
+          *d = overwrite ? v : *d + v;
+        } else {
+          stage[r * C2_XW + col + n] = f2bf(v);
+        }
+      }
+  };
+  // the backward GEMM of one layer in two passes: first the column tiles the PARTNER owns (published at once, so the
+  // hand-off flies during the second pass), then the own ones; then the partner's partials are added
+  auto layer_gemm = [&](int layer, __amdgpu_buffer_rsrc_t wr, int ep) {
+    const bool l2 = layer == 1;
+    const bool xw = !l2 && wave < 4;                   // this wave also has a d x tile (slot 2)
+    const int xo = wave >> 1;                          // ... owned by CU xo
+    for (int pass = 0; pass < 2; ++pass) {
+      const int who = pass == 0 ? pcu : cu;            // owner of the tiles of this pass
+      const int s0 = who, s1 = l2 ? who + 2 : 2;
+      const bool two = l2 || (xw && xo == who);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto side = [](int) {};
+      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, side);
+      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, side);
+      if (l2) { if (pass == 0) { C2T(3) } else { C2T(6) } }
+      scatter(acc[0], s0, layer);
+      if (two) scatter(acc[1], s1, layer);
+      if (pass == 0) {
+        __syncthreads();                               // staging slab complete
+        if (l2) { C2T(4) }
+        publish(layer, ep);
+        if (l2) { C2T(5) }
+      }
+    }
+    if (l2) { C2T(7) }
+    consume(layer, ep);                                // (barrier inside: own partials complete before the adds)
+    __syncthreads();
+    if (l2) { C2T(8) }
+  };
+
+  Saved sv2, sv1;
+  fetch(sv2, g2, c2, dh2, a.Tn - 1);
+#ifdef C2_STAMP
+  st_last = __builtin_readcyclecounter();
+#endif
+
+#pragma unroll 1
+  for (int t = a.Tn - 1; t >= 0; --t) {
+    const int ep = a.Tn - t;
+    // ---------------- LSTM layer 2 (exchange layer index 1)
+    cell_bwd(sv2, dhrec2, true, dc2, t, dg2T);
+    C2T(0)
+    __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
+    C2T(1)
+    fetch(sv1, g1, c1, nullptr, t);                    // layer-1 state of this step: lands during the GEMM
+    C2T(2)
+    layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
+    // ---------------- LSTM layer 1 (exchange layer index 0)
+    cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
+    C2T(9)
+    __syncthreads();
+    fetch(sv2, g2, c2, dh2, t - 1);                    // layer-2 state of the next (earlier) step
+    C2T(10)
+    layer_gemm(0, wr1, ep);                            // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
+    C2T(11)
+    for (int i = tid; i < MC * 32; i += NT) {
+      const int r = i / 32, c = i % 32;
+      if (row0 + r < N) store1_nt<T>(dx + ((size_t)t * N + row0 + r) * KX + cu * 32 + c, dxbuf[i]);
+    }
+    // (dxbuf is rewritten by the next layer-1 GEMM only, several barriers later)
+  }
+#ifdef C2_STAMP
+  C2_STAMP_FINI
+#endif
+}
+
+// packed weights of the K-split backward: element (cu, wave, kk, slot, lane l, j)
+//   local k = 32*kk + 8*(l>>4) + j = ul*4 + g'  (unit u = cu*192 + ul, g' in i,g,f,o -> torch block {0,2,1,3}[g'])
+//   column tile tau = wave + 12*slot, column c = 16*tau + (l&15)
+//   LSTM layer 2: c < 384 -> W_ih[row][c] (input feature h1 unit c); else W_hh[row][c-384]
+//   LSTM layer 1: c < 384 -> W_hh[row][c];  384 <= c < 448 -> W_ih[row][c-384] (0 for c-384 >= I);  tau >= 28 -> 0
+__global__ void lstm_coop_pack_bwd2_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, bf16_t* __restrict__ out,
+                                           int I, int layer) {
+  const size_t total = (size_t)CB_G * CB_NW * C2_NKK * C2_SLOTS * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = e & 7, l = (e >> 3) & 63;
+    size_t f = e >> 9;
+    const int slot = f % C2_SLOTS; f /= C2_SLOTS;
+    const int kk = f % C2_NKK; f /= C2_NKK;
+    const int wave = f % CB_NW;
+    const int cu = (int)(f / CB_NW);
+    const int k = 32 * kk + 8 * (l >> 4) + j;
+    const int ul = k >> 2, gp = k & 3;
+    const int tg = gp == 0 ? 0 : (gp == 1 ? 2 : (gp == 2 ? 1 : 3));
+    const int row = tg * CB_H + cu * CB_HC + ul;
+    const int c = 16 * (wave + CB_NW * slot) + (l & 15);
+    float v = 0.f;
+    if (layer == 2) {
+      v = c < CB_H ? w_ih[(size_t)row * CB_H + c] : w_hh[(size_t)row * CB_H + (c - CB_H)];
+    } else if (c < CB_H) {
+      v = w_hh[(size_t)row * CB_H + c];
+    } else if (c < CB_H + CB_KX) {
+      const int xc = c - CB_H;
+      v = xc < I ? w_ih[(size_t)row * I + xc] : 0.f;
+    }
+    out[e] = f2bf(v);
+  }
+}
+
 template <typename T, int G, int MT, bool TRAIN>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
@@ -814,6 +1180,45 @@ int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const vo
     return NPPC_ELAUNCH;
   if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   hipLaunchKernelGGL(lstm2_coop_bwd_kernel, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// K-split cooperative backward (lstm2_coop_bwd2_kernel): same tensor contract as nppc_lstm2_bwd_coop; xch holds
+// clusters*2*2*2*32*384 bf16 partial sums, flags clusters*4 + 4 u32 (zeroed by the launcher)
+int nppc_lstm2_coop_bwd2_packed_elems(long* n) {
+  *n = (long)CB_G * CB_NW * C2_NKK * C2_SLOTS * 512;
+  return NPPC_OK;
+}
+
+int nppc_lstm2_coop_bwd2_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                              void* wb2, void* stream) {
+  if (!w_ih0 || !w_hh0 || !w_ih1 || !w_hh1 || !wb1 || !wb2 || I > CB_KX) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_coop_pack_bwd2_kernel, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (bf16_t*)wb1, I, 1);
+  hipLaunchKernelGGL(lstm_coop_pack_bwd2_kernel, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (bf16_t*)wb2, CB_H, 2);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
+                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
+                         int Tn, int n_cu, void* stream) {
+  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1 || !dg2 || !xch || !flags || N <= 0 || Tn <= 0)
+    return NPPC_EBADARG;
+  const int clusters = (int)((N + CB_MC - 1) / CB_MC);
+  if (clusters * CB_G > n_cu) return NPPC_EUNSUPPORTED;      // every workgroup of a cluster must be resident
+  if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * C2_XW * 2) return NPPC_EBADARG;
+  CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
+                          (size_t)CB_MC * C2_XW * 2;
+  static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem) != hipSuccess)
+    return NPPC_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  hipLaunchKernelGGL(lstm2_coop_bwd2_kernel, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

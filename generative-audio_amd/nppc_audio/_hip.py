@@ -74,6 +74,9 @@ SIGS = {
     "nppc_lstm2_coop_bwd_packed_elems": [PL],
     "nppc_lstm2_coop_bwd_pack": [P, P, P, P, I, P, P, P],
     "nppc_lstm2_bwd_coop": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
+    "nppc_lstm2_coop_bwd2_packed_elems": [PL],
+    "nppc_lstm2_coop_bwd2_pack": [P, P, P, P, I, P, P, P],
+    "nppc_lstm2_bwd_coop2": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],
     "nppc_lstm2_pack_weights_bwd": [I, P, P, P, P, I, I, P, P, P],
     "nppc_lstm2_bwd": [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],

@@ -79,6 +79,7 @@ def workspace(key, shape, dtype, device, zero=False):
     return t
 
 
+COOP_BWD_KSPLIT = True    # cooperative backward variant: True = K-split (bf16 partial-sum exchange), False = output-split
 WGRAD_SPLITS = 64    # K-slices of the weight-gradient GEMMs (engine._lstm_wgrad)
 ROW_PAD = 64 * WGRAD_SPLITS   # row granularity of their operands: 64-row stages x K-slices; buffers carry this much slack
 
@@ -158,12 +159,18 @@ class PackedLSTMBwd:
             H.call("nppc_lstm2_coop_bwd_packed_elems", ctypes.byref(nc))
             self.cwb1 = torch.empty(nc.value, dtype=dt, device=device)
             self.cwb2 = torch.empty(nc.value, dtype=dt, device=device)
+            H.call("nppc_lstm2_coop_bwd2_packed_elems", ctypes.byref(nc))
+            self.kwb1 = torch.empty(nc.value, dtype=dt, device=device)     # K-split variant
+            self.kwb2 = torch.empty(nc.value, dtype=dt, device=device)
 
     def pack(self, w_ih0, w_hh0, w_ih1, w_hh1):
         ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, w_ih1, w_hh1)]
         H.call("nppc_lstm2_pack_weights_bwd", self.prec, *ws, self.I, self.Hd, self.wb1, self.wb2, H.stream())
         if self.coop:
-            H.call("nppc_lstm2_coop_bwd_pack", *ws, self.I, self.cwb1, self.cwb2, H.stream())
+            if COOP_BWD_KSPLIT:
+                H.call("nppc_lstm2_coop_bwd2_pack", *ws, self.I, self.kwb1, self.kwb2, H.stream())
+            else:
+                H.call("nppc_lstm2_coop_bwd_pack", *ws, self.I, self.cwb1, self.cwb2, H.stream())
         return self
 
 
@@ -178,6 +185,14 @@ def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
     dg1 = workspace(tag + ("dg1",), (Rp, 4 * Hd), dt, dev, zero=True)
     dg2 = workspace(tag + ("dg2",), (Rp, 4 * Hd), dt, dev, zero=True)
     use_coop = (COOP if coop is None else coop) and packed_bwd.coop and ((N + 31) // 32) * 2 <= _n_cu()
+    if use_coop and COOP_BWD_KSPLIT:
+        ncl = (N + 31) // 32
+        xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 384,), dt, dev)
+        flags = workspace(tag + ("coop_flags",), (ncl * 4 + 4,), torch.int32, dev, zero=True)
+        _timed(("lstm2_bwd_coop_ksplit", 1, N, Tn, 2), lambda: H.call(
+            "nppc_lstm2_bwd_coop2", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.kwb1, packed_bwd.kwb2,
+            dx, dg1, dg2, xch, xch.numel() * xch.element_size(), flags, N, Tn, _n_cu(), H.stream()))
+        return dx, dg1, dg2
     if use_coop:
         ncl = (N + 31) // 32
         xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 768,), dt, dev)

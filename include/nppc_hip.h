@@ -132,6 +132,14 @@ int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float
 int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
                         int Tn, int n_cu, void* stream);
+/* K-split variant of the cooperative backward (each CU multiplies its own gate-gradient half with all output columns and
+ * the pair exchanges bf16 partial sums: 38 KB per step instead of 96 KB); same tensor contract */
+int nppc_lstm2_coop_bwd2_packed_elems(long* n);
+int nppc_lstm2_coop_bwd2_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                              void* wb2, void* stream);
+int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
+                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
+                         int Tn, int n_cu, void* stream);
 int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
 int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
                                 int I, int H, void* wb1, void* wb2, void* stream);
