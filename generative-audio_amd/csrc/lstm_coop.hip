@@ -1023,19 +1023,25 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 #pragma unroll 1
   for (int t = a.Tn - 1; t >= 0; --t) {
     const int ep = a.Tn - t;
+    // The saved state of the NEXT phase is requested right before each cell phase (ALU + LDS only, ~2 us): loads, stores
+    // and the weight-fragment ring share one in-order vmcnt queue, so HBM loads issued in front of a GEMM made its
+    // first weight fragments wait out the HBM latency (~8 us per step); the wait for THIS phase's state, issued a
+    // whole layer earlier, leaves the younger loads in flight.  (Measured: issuing one phase's 84 KB of state loads
+    // occupies a CU's memory queue for ~12k cycles -- per-CU miss parallelism, not chip-wide HBM contention: starting
+    // the clusters an eighth of a step apart changed nothing.)
     // ---------------- LSTM layer 2 (exchange layer index 1)
+    fetch(sv1, g1, c1, nullptr, t);                    // layer-1 state of this step
     cell_bwd(sv2, dhrec2, true, dc2, t, dg2T);
     C2T(0)
     __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
     C2T(1)
-    fetch(sv1, g1, c1, nullptr, t);                    // layer-1 state of this step: lands during the GEMM
     C2T(2)
     layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
     // ---------------- LSTM layer 1 (exchange layer index 0)
+    fetch(sv2, g2, c2, dh2, t - 1);                    // layer-2 state of the next (earlier) step
     cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
     C2T(9)
     __syncthreads();
-    fetch(sv2, g2, c2, dh2, t - 1);                    // layer-2 state of the next (earlier) step
     C2T(10)
     layer_gemm(0, wr1, ep);                            // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
     C2T(11)
