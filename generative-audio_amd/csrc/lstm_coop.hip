@@ -153,6 +153,12 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   constexpr int SLICE_CH = SLICE * (int)sizeof(T) / 16;           // 16-byte chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
+  // TRAIN: the cell states of the two layers are staged here ([MC][HC] each) and, like the h slices that are in LDS
+  // anyway, leave for HBM as coalesced 16-byte non-temporal stores after the step's barriers; as 2-byte stores from the
+  // accumulator lanes (32-byte pieces of a line) the saved state cost 18 % of the kernel.  Gates go straight from the
+  // lanes: 8 bytes x 16 consecutive units = full 128-byte lines.
+  T* sc1 = lds + (size_t)MC * RS;
+  T* sc2 = sc1 + MC * HC;
 
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,6 +213,17 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   T* c1o = reinterpret_cast<T*>(a.c1);
   T* c2o = reinterpret_cast<T*>(a.c2);
 
+  // TRAIN: own [MC][HC] slices of h (LDS columns hoff + cu*HC) and c (staging) of step t -> HBM, 16 bytes per lane
+  auto flush_state = [&](T* ho, T* co, const T* sc, int hoff, int t) {
+    for (int ch = tid; ch < SLICE_CH; ch += NT) {
+      const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
+      if (row0 + r < N) {
+        const size_t e = ((size_t)t * N + row0 + r) * H + cu * HC + cc * VEC;
+        st_nt16(ho + e, *reinterpret_cast<const u32x4*>(lds + r * RS + hoff + cu * HC + cc * VEC));
+        st_nt16(co + e, *reinterpret_cast<const u32x4*>(sc + r * HC + cc * VEC));
+      }
+    }
+  };
   // publish this CU's h slice (already in LDS columns [hoff + cu*HC, +HC)) of layer `layer` for epoch `ep`
   auto publish = [&](int layer, int hoff, int ep) {
     const int par = ep & 1;
@@ -344,9 +361,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           hn1[mt][j] = ov * tanh_f(cn);
           if (TRAIN && rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
-            store1_nt<T>(c1o + e, cn);
+#ifndef CF_NO_SAVE
+            sc1[(4 * q + 16 * mt + j) * HC + wave * 16 + n] = from_f32<T>(cn);
             store4_nt<T>(g1o + e * 4, iv1[mt][j], gv1[mt][j], fv, ov);
-            store1_nt<T>(h1o + e, hn1[mt][j]);
+#endif
           }
         }
     }
@@ -381,6 +399,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     }
     __syncthreads();                                              // (2a) own h1_t slice complete in LDS
     publish(0, OH1, ep);
+#ifndef CF_NO_SAVE
+    if (TRAIN) flush_state(h1o, c1o, sc1, OH1, t);                // after the hand-off drain, not in front of it
+#endif
     // ================= layer 2 =================
     // gate pair (i,g): the h2_{t-1} half first -- it does not need the partners' h1_t, so it hides the hand-off latency
     f32x4 ig2[MT];
@@ -422,10 +443,12 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           hn2[mt][j] = ov * tanh_f(cn);
           if (rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
-            store1_nt<T>(h2o + e, hn2[mt][j]);
+            if (!TRAIN) store1_nt<T>(h2o + e, hn2[mt][j]);
             if (TRAIN) {
-              store1_nt<T>(c2o + e, cn);
+#ifndef CF_NO_SAVE
+              sc2[(4 * q + 16 * mt + j) * HC + wave * 16 + n] = from_f32<T>(cn);
               store4_nt<T>(g2o + e * 4, iv2[mt][j], gv2[mt][j], fv, ov);
+#endif
             }
           }
         }
@@ -437,6 +460,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int j = 0; j < 4; ++j) hw_lane[OH2 + (16 * mt + j) * RS] = from_f32<T>(hn2[mt][j]);
     __syncthreads();                                              // own h2_t slice complete in LDS
     if (more) publish(1, OH2, ep);
+#ifndef CF_NO_SAVE
+    if (TRAIN) flush_state(h2o, c2o, sc2, OH2, t);
+#endif
   }
 }
 
@@ -1093,7 +1119,7 @@ template <typename T, int G, int MT, bool TRAIN>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
   constexpr int RS = 2 * KX + 2 * H + 16 / (int)sizeof(T);
-  size_t smem = (size_t)MC * RS * sizeof(T);
+  size_t smem = (size_t)MC * RS * sizeof(T) + (TRAIN ? (size_t)2 * MC * (H / G) * sizeof(T) : 0);
   if (smem < 84 * 1024) smem = 84 * 1024;            // > half a CU's LDS: at most one workgroup per CU
   if (smem > 160 * 1024) return NPPC_EUNSUPPORTED;
   const long need = (long)a.clusters * 2 * 2 * G * MC * (H / G) * sizeof(T);
