@@ -213,14 +213,14 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   T* c1o = reinterpret_cast<T*>(a.c1);
   T* c2o = reinterpret_cast<T*>(a.c2);
 
-  // TRAIN: own [MC][HC] slices of h (LDS columns hoff + cu*HC) and c (staging) of step t -> HBM, 16 bytes per lane
+  // own [MC][HC] slices of h (LDS columns hoff + cu*HC) and, TRAIN, c (staging) of step t -> HBM, 16 bytes per lane
   auto flush_state = [&](T* ho, T* co, const T* sc, int hoff, int t) {
     for (int ch = tid; ch < SLICE_CH; ch += NT) {
       const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
       if (row0 + r < N) {
         const size_t e = ((size_t)t * N + row0 + r) * H + cu * HC + cc * VEC;
         st_nt16(ho + e, *reinterpret_cast<const u32x4*>(lds + r * RS + hoff + cu * HC + cc * VEC));
-        st_nt16(co + e, *reinterpret_cast<const u32x4*>(sc + r * HC + cc * VEC));
+        if (TRAIN) st_nt16(co + e, *reinterpret_cast<const u32x4*>(sc + r * HC + cc * VEC));
       }
     }
   };
@@ -443,7 +443,6 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           hn2[mt][j] = ov * tanh_f(cn);
           if (rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
-            if (!TRAIN) store1_nt<T>(h2o + e, hn2[mt][j]);
             if (TRAIN) {
 #ifndef CF_NO_SAVE
               sc2[(4 * q + 16 * mt + j) * HC + wave * 16 + n] = from_f32<T>(cn);
@@ -461,7 +460,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     __syncthreads();                                              // own h2_t slice complete in LDS
     if (more) publish(1, OH2, ep);
 #ifndef CF_NO_SAVE
-    if (TRAIN) flush_state(h2o, c2o, sc2, OH2, t);
+    flush_state(h2o, c2o, sc2, OH2, t);                           // inference: h2 only (the head reads it)
 #endif
   }
 }
