@@ -180,7 +180,7 @@ def main():
         "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"{'C2' if (a.batch, a.seconds, a.dirs) == (BATCH, SECONDS, K_DIRS) else 'custom'}: speech-enhancement NPPC, FullSubNet+ restorer + K={K_DIRS} direction net, "
+        "config": {"workload": f"{'C2' if (a.batch, a.seconds, a.dirs) == (BATCH, SECONDS, K_DIRS) else ('C5' if (a.batch, a.seconds, a.dirs) == (8, 30, 8) else 'custom')}: speech-enhancement NPPC, FullSubNet+ restorer + K={a.dirs} direction net, "
                                f"batch={a.batch}x{a.seconds:g}s@16kHz per GPU, STFT {NFFT}/{HOP}, G_rest=1 G_pc=2, "
                                f"full train step (fwd+loss+bwd+Adam{'+RCCL all-reduce' if world > 1 else ''})",
                    "global_batch": a.batch * world, "frames_per_step_per_gpu": frames,
