@@ -1143,13 +1143,16 @@ extern "C" {
 int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, int* mtile, int* clusters) {
   *G = 0; *mtile = 0; *clusters = 0;
   if (prec != NPPC_PREC_BF16 || H != 384 || N <= 0) return NPPC_OK;
-  // candidates (G, mtile), most CUs first: the stream per CU shrinks with G, the rows per cluster grow with mtile
-  const int cand[3][2] = {{2, 2}, {4, 4}, {2, 5}};   // measured at N = 4096: G = 2 beats G = 4 (6 waves leave two SIMDs idle)
-  for (int oi = 0; oi < 3; ++oi) {
+  // candidates (G, mtile): the weight stream per CU shrinks with G, the rows per cluster grow with mtile.  Take the one
+  // that occupies the most CUs (all workgroups of a launch must be resident: clusters * G <= n_cu); ties go to the
+  // earlier entry (measured at N = 4096: G = 2 beats G = 4, whose 6 waves leave two SIMDs idle).
+  const int cand[4][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 5}};
+  long best = 0;
+  for (int oi = 0; oi < 4; ++oi) {
     const int g = cand[oi][0], mt = cand[oi][1];
     if (train && mt == 5) continue;
     const long cl = (N + 16 * mt - 1) / (16 * mt);
-    if (cl * g <= n_cu && (cl * g * 2 > n_cu || oi == 2)) { *G = g; *mtile = mt; *clusters = (int)cl; return NPPC_OK; }
+    if (cl * g <= n_cu && cl * g > best) { best = cl * g; *G = g; *mtile = mt; *clusters = (int)cl; }
   }
   return NPPC_OK;
 }
@@ -1165,8 +1168,11 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
   CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC)};
   hipStream_t s = (hipStream_t)stream;
   if (G == 4) {
-    if (mtile != 4) return NPPC_EUNSUPPORTED;
-    return train ? launch_coop<bf16_t, 4, 4, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 4, 4, false>(a, (size_t)xch_bytes, s);
+    if (mtile == 4)
+      return train ? launch_coop<bf16_t, 4, 4, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 4, 4, false>(a, (size_t)xch_bytes, s);
+    if (mtile == 2)
+      return train ? launch_coop<bf16_t, 4, 2, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 4, 2, false>(a, (size_t)xch_bytes, s);
+    return NPPC_EUNSUPPORTED;
   }
   if (train) {
     if (mtile == 2) return launch_coop<bf16_t, 2, 2, true>(a, (size_t)xch_bytes, s);
