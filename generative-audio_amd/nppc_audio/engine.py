@@ -102,7 +102,7 @@ class FSNEngine:
         self.C = n_maps * num_freqs
         self.ldC = rup(self.C, 64)
         self.ldF = rup(num_freqs, 64)
-        self.KC = rup(self.C, 32)
+        self.KC = self.ldC                     # K of the input GEMMs: the zero-padded row width (multiple of 64: LDS-staged GEMM path)
         self.dev = flat.flat.device
         self.I = 2 * sb_neighbors + 1 + 3
         self.sP = flat.branch_stride()
