@@ -661,7 +661,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                long ldb, float* __restrict__ C, long ldc, long slab_stride,
-                                                               long Rz, int ntap, int Wp, int shift_a) {
+                                                               long Rz, int ntap, int Wp, int shift_a, int nzb, long bsA,
+                                                               long bsB, long bsC) {
   constexpr int BM = 128, BR = 64;
   constexpr int RSA = BM + 8, RSB = BN + 8;                 // LDS row strides (elements): 16-byte aligned rows
   constexpr int WN = BN / 2;                                // columns per wave (2x2 waves)
@@ -682,10 +683,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
     bx = t % gridDim.x;
     by = t / gridDim.x;
   }
+  // batches (independent problems, e.g. the three full-band branches): bz = batch * nzb + (tap * ksplit + slice)
+  const unsigned bb = bz / nzb;
+  bz %= nzb;
+  A += (size_t)bb * bsA;
+  B += (size_t)bb * bsB;
+  C += (size_t)bb * bsC;
   const long m0 = (long)bx * BM, n0 = (long)by * BN;
   // bz = tap * ksplit + slice: tap t reads B (or A, shift_a) shifted by (t/3 - 1) * Wp + (t%3 - 1) rows (3x3 convolution
   // weight gradient: nine row-shifted products in one launch); ntap == 1 is the plain split-K GEMM
-  const int ksl = gridDim.z / ntap, tap = bz / ksl;
+  const int ksl = nzb / ntap, tap = bz / ksl;
   const long rbase = (long)(bz % ksl) * Rz;
   const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
   const bf16_t* Ab = A + (rbase + (shift_a ? boff : 0)) * lda + m0;
@@ -785,18 +792,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
 // C_slab[z] [M][N] = A[rows slice z][M]^T * B[rows slice z][N]  (bf16 operands, fp32 slabs).  M % 128 == 0,
 // N % 64 == 0, R % (64*ksplit) == 0, lda/ldb multiples of 8.
 static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
-                     int ntap, int Wp, int shift_a, void* stream) {
+                     int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (N % 128 == 0) {
-    dim3 grid(M / 128, N / 128, ksplit * ntap);
+    dim3 grid(M / 128, N / 128, ksplit * ntap * batch);
     hipLaunchKernelGGL(gemm_tn_tiled_kernel<128>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a);
+                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a, ksplit * ntap, sA, sB, sC);
   } else {
-    dim3 grid(M / 128, N / 64, ksplit * ntap);
+    dim3 grid(M / 128, N / 64, ksplit * ntap * batch);
     hipLaunchKernelGGL(gemm_tn_tiled_kernel<64>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
-                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a);
+                       (long)M * ldc, R / ksplit, ntap, Wp, shift_a, ksplit * ntap, sA, sB, sC);
   }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
@@ -805,6 +812,13 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
 extern "C" int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
                                    int ksplit, void* stream) {
   return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream);
+}
+
+// `batch` independent products in one launch (operand / slab strides in elements; slabs of batch b start at C + b*sC)
+extern "C" int nppc_gemm_tn_splitk_batched(const void* A, long lda, long sA, const void* B, long ldb, long sB, float* C, long ldc,
+                                           long sC, int M, int N, long R, int ksplit, int batch, void* stream) {
+  if (batch < 1) return NPPC_EBADARG;
+  return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream, batch, sA, sB, sC);
 }
 
 // Nine row-shifted TN products in one launch (3x3 convolution weight gradient, csrc/unet.hip):

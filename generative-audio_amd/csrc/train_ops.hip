@@ -207,6 +207,28 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int S, long
   }
 }
 
+// dst[b][r][c] = sum_s slabs[b][s][c][r]   (transposed reduction: the slabs hold the gradient's transpose)
+__global__ void reduce_slabs_t_kernel(const float* __restrict__ slabs, int S, long slab_stride, long ld, float* __restrict__ dst,
+                                      long dst_ld, int rows, int ncols, long sSlab, long sDst) {
+  slabs += (size_t)blockIdx.z * sSlab;
+  dst += (size_t)blockIdx.z * sDst;
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows of 32 per pass
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;                          // slab element [c][r]
+    float a = 0.f;
+    if (c < ncols && r < rows)
+      for (int s = 0; s < S; ++s) a += slabs[(size_t)s * slab_stride + (size_t)c * ld + r];
+    tile[i][tx] = a;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < ncols) dst[(size_t)r * dst_ld + c] = tile[tx][i];
+  }
+}
+
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, no amsgrad)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
@@ -317,6 +339,15 @@ int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, floa
   const int gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1, batch), dim3(256), 0, (hipStream_t)stream, slabs, S, slab_stride, ld,
                      dst, dst_ld, rows, col0, ncols, permH, accumulate, sSlab, sDst);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_reduce_slabs_t(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int ncols,
+                        long sSlab, long sDst, int batch, void* stream) {
+  if (!slabs || !dst || S < 1 || rows <= 0 || ncols <= 0 || batch < 1) return NPPC_EBADARG;
+  hipLaunchKernelGGL(reduce_slabs_t_kernel, dim3(ceil_div(ncols, 32), ceil_div(rows, 32), batch), dim3(256), 0,
+                     (hipStream_t)stream, slabs, S, slab_stride, ld, dst, dst_ld, rows, ncols, sSlab, sDst);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

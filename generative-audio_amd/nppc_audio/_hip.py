@@ -92,6 +92,8 @@ SIGS = {
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],
     "nppc_gemm_tn_splitk": [P, L, P, L, P, L, I, I, L, I, P],
+    "nppc_gemm_tn_splitk_batched": [P, L, L, P, L, L, P, L, L, I, I, L, I, I, P],
+    "nppc_reduce_slabs_t": [P, I, L, L, P, L, I, I, L, L, I, P],
     "nppc_gemm_tn_splitk_taps": [P, L, P, L, P, L, I, I, L, I, I, I, P],
     "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],

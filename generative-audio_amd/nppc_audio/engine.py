@@ -424,6 +424,8 @@ class FSNEngine:
                X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
         # ---- 6. TCN blocks in reverse
         sAct = B * Tp * TCN_HIDDEN
+        # bf16: the 1x1-conv weight gradients run on the TN GEMM straight from the row-major activations (no transposes)
+        tn_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
         Sgn = ws("Sgn", (3, B, 2), torch.float64)
@@ -437,10 +439,17 @@ class FSNEngine:
             # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
             H.call("nppc_tcn_gn_apply", prec, y2, d["a2"], st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), B,
                    TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
-            H.call("nppc_transpose", prec, dXo, tA, R, ldC, ldC, R, R * ldC, sTA, 0, 3, s)
-            H.call("nppc_transpose", prec, d["a2"], tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
-            self._wgrad(tA, R, sTA, tB, R, sTB, Cr, TCN_HIDDEN, R, S2, pre + "sconv.weight", TCN_HIDDEN, C, TCN_HIDDEN, slab2,
-                        batch=3, sDst=sP)
+            if tn_ok:
+                # row-major operands as they are: slab[k][c] = sum_r a2[r][k] * dXo[r][c] = dW2^T, transposed in the reduction
+                H.call("nppc_gemm_tn_splitk_batched", d["a2"], TCN_HIDDEN, sAct, dXo, ldC, R * ldC, slab2, ldC,
+                       S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, s)
+                H.call("nppc_reduce_slabs_t", slab2, S2, TCN_HIDDEN * ldC, ldC, self.g(pre + "sconv.weight"), TCN_HIDDEN, C,
+                       TCN_HIDDEN, S2 * TCN_HIDDEN * ldC, sP, 3, s)
+            else:
+                H.call("nppc_transpose", prec, dXo, tA, R, ldC, ldC, R, R * ldC, sTA, 0, 3, s)
+                H.call("nppc_transpose", prec, d["a2"], tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
+                self._wgrad(tA, R, sTA, tB, R, sTB, Cr, TCN_HIDDEN, R, S2, pre + "sconv.weight", TCN_HIDDEN, C, TCN_HIDDEN,
+                            slab2, batch=3, sDst=sP)
             # dA2 = dXo W2
             H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
                    sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
@@ -458,10 +467,17 @@ class FSNEngine:
                    Tv, 1e-8, sAct, B * 2, sP, 3, s)
             # conv1x1: bias, weight, input gradients
             H.call("nppc_colsum", prec, h2b, self.g(pre + "conv1x1.bias"), R, TCN_HIDDEN, TCN_HIDDEN, sAct, sP, 3, s)
-            H.call("nppc_transpose", prec, h2b, tA, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTA, 0, 3, s)
-            H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
-            self._wgrad(tA, R, sTA, tB, R, sTB, TCN_HIDDEN, ldC, R, S2, pre + "conv1x1.weight", C, TCN_HIDDEN, C, slab2, batch=3,
-                        sDst=sP)
+            if tn_ok:
+                # slab[k][c] = sum_r dpre1[r][k] * Xin[r][c] = dW1
+                H.call("nppc_gemm_tn_splitk_batched", h2b, TCN_HIDDEN, sAct, Xin, ldC, R * ldC, slab2, ldC,
+                       S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, s)
+                H.call("nppc_reduce_slabs", slab2, S2, TCN_HIDDEN * ldC, ldC, self.g(pre + "conv1x1.weight"), C, TCN_HIDDEN, 0,
+                       C, 0, 0, S2 * TCN_HIDDEN * ldC, sP, 3, s)
+            else:
+                H.call("nppc_transpose", prec, h2b, tA, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTA, 0, 3, s)
+                H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
+                self._wgrad(tA, R, sTA, tB, R, sTB, TCN_HIDDEN, ldC, R, S2, pre + "conv1x1.weight", C, TCN_HIDDEN, C, slab2,
+                            batch=3, sDst=sP)
             H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
                    R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
             dXo, dXi = dXi, dXo

@@ -71,6 +71,8 @@ int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long l
  * LDS tiles read back with ds_read_b64_tr_b16; M % 128 == 0, N % 64 == 0, R % (64*ksplit) == 0 */
 int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                         void* stream);
+int nppc_gemm_tn_splitk_batched(const void* A, long lda, long sA, const void* B, long ldb, long sB, float* C, long ldc, long sC,
+                                int M, int N, long R, int ksplit, int batch, void* stream);
 int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
                              int ksplit, int Wp, int shift_a, void* stream);
 int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
@@ -90,6 +92,8 @@ int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long
                    int relu, int batch, void* stream);
 int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
                 void* stream);
+int nppc_reduce_slabs_t(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int ncols,
+                        long sSlab, long sDst, int batch, void* stream);
 int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int col0,
                       int ncols, int permH, int accumulate, long sSlab, long sDst, int batch, void* stream);
 
