@@ -87,13 +87,34 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /
     for (int s = 0; s < 2; ++s) b[s] = BFrag<T>::load(wr, lane, frag_boff<T>(gp, ublk, koff + kk, s, nk));
   };
   auto compute = [&](const frag(&b)[2], int kk) {
-    frag af[MT];
+    if constexpr (MT <= 3) {
+      frag af[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[mt] = load_frag<T>(a_lane + 16 * mt * RS + 32 * kk);
+      for (int mt = 0; mt < MT; ++mt) af[mt] = load_frag<T>(a_lane + 16 * mt * RS + 32 * kk);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mma16(af[mt], b[s], acc[s][mt]);
+        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mma16(af[mt], b[s], acc[s][mt]);
+    } else {
+      constexpr int AG = 2;
+      // many row tiles: A fragments in groups of AG with a scheduling fence in between, so that at most 4*AG (not
+      // 4*MT, twice that when the scheduler hoists the next k-step's reads) VGPRs hold A operands -- the 80-row
+      // variant spilled its layer-2 cell state otherwise, and ANY scratch reload waits for every outstanding
+      // memory operation of the wave (hand-off stores, HBM streams)
+#pragma unroll
+      for (int m0 = 0; m0 < MT; m0 += AG) {
+        frag af[AG];
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+          if (m0 + i < MT) af[i] = load_frag<T>(a_lane + 16 * (m0 + i) * RS + 32 * kk);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < AG; ++i)
+            if (m0 + i < MT) acc[s][m0 + i] = mma16(af[i], b[s], acc[s][m0 + i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   };
   frag b[DEPTH][2];
   const int n = k1 - k0;
@@ -140,8 +161,18 @@ template <> __device__ __forceinline__ void store4_nt<bf16_t>(bf16_t* p, float a
 template <typename T> __device__ __forceinline__ void store1_nt(T* p, float v) { __builtin_nontemporal_store(from_f32<T>(v), p); }
 
 // LDS row (elements): [X0 (KX) | X1 (KX) | H1 (H) | H2 (H)] + pad.  H = 384 = 12 k-steps.
+// diagnostic phase timers of the forward kernel (tools/diag/stamp_fwd.py builds with -DCF_STAMP)
+#ifdef CF_STAMP
+#define FT(i) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long nw = __builtin_readcyclecounter(); ft_acc[i] += nw - ft_last; ft_last = nw; }
+#else
+#define FT(i)
+#endif
+
 template <typename T, int G, int MT, int KX, bool TRAIN>
 __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(CoopArgs a) {
+#ifdef CF_STAMP
+  unsigned long long ft_last = __builtin_readcyclecounter(), ft_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   constexpr int H = 384, HC = H / G, NW = HC / 16, NT = NW * 64, MC = 16 * MT;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int RS = 2 * KX + 2 * H + VEC;
@@ -172,17 +203,30 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   const long rbase = row0 + 4 * q;
 
   for (int i = tid; i < MC * RS; i += NT) lds[i] = from_f32<T>(0.f);
+  // biases: registers (8 VGPRs) for the small tiles; for MT > 3, where registers are short, the own units' biases live
+  // in LDS ([2 layers][4 gates][HC] floats) and are read in the pointwise stages
+  constexpr bool BIAS_LDS = MT > 3;
+  float* bl = reinterpret_cast<float*>(sc1 + (TRAIN ? 2 * MC * HC : 0));
   float b1[4], b2[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     b1[g] = a.bias1[g * H + unit_n];
     b2[g] = a.bias2[g * H + unit_n];
+    if (BIAS_LDS && q == 0) {
+      bl[(0 * 4 + g) * HC + wave * 16 + n] = b1[g];
+      bl[(1 * 4 + g) * HC + wave * 16 + n] = b2[g];
+    }
   }
+  auto bias = [&](int layer, int g) -> float {
+    if constexpr (BIAS_LDS) return bl[(layer * 4 + g) * HC + wave * 16 + n];
+    else return layer ? b2[g] : b1[g];
+  };
   f32x4 c1[MT], c2[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) c1[mt] = c2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const T* xg = reinterpret_cast<const T*>(a.x);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.Tn * N * KX * sizeof(T)));
   constexpr int cpr = KX / VEC, nchunk = MC * cpr;
   constexpr int XCH = (nchunk + NT - 1) / NT;
   __syncthreads();
@@ -215,7 +259,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 
   // own [MC][HC] slices of h (LDS columns hoff + cu*HC) and, TRAIN, c (staging) of step t -> HBM, 16 bytes per lane
   auto flush_state = [&](T* ho, T* co, const T* sc, int hoff, int t) {
-    for (int ch = tid; ch < SLICE_CH; ch += NT) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));           // re-derive the chunk addresses each step (hoisted, they were spilled)
+    for (int ch = tv; ch < SLICE_CH; ch += NT) {
       const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
       if (row0 + r < N) {
         const size_t e = ((size_t)t * N + row0 + r) * H + cu * HC + cc * VEC;
@@ -228,7 +274,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   auto publish = [&](int layer, int hoff, int ep) {
     const int par = ep & 1;
     const int base = ((layer * 2 + par) * G + cu) * SLICE * (int)sizeof(T);
-    for (int ch = tid; ch < SLICE_CH; ch += NT) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    for (int ch = tv; ch < SLICE_CH; ch += NT) {
       const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + r * RS + hoff + cu * HC + cc * VEC);
       store_sc1_b128(xr, base + ch * 16, v);
@@ -258,7 +306,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     for (int p = 0; p < G; ++p) {
       if (p == cu) continue;
       const int base = ((layer * 2 + par) * G + p) * SLICE * (int)sizeof(T);
-      for (int ch = tid; ch < SLICE_CH; ch += NT) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      for (int ch = tv; ch < SLICE_CH; ch += NT) {
         const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
         const u32x4 v = load_sc1_b128(xr, base + ch * 16);
         *reinterpret_cast<u32x4*>(lds + r * RS + hoff + p * HC + cc * VEC) = v;
@@ -293,34 +343,34 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     const int p = t & 1;
     const int ep = t + 1;
     const size_t ebase = ((size_t)t * N + rbase) * H + unit_n;
-    u32x4 hx[HXC];
     if (t > 0) {
+      // partners' h2_{t-1} slices: global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`), one row of a slice
+      // (HC bf16 = HC/8 lanes x 16 bytes, landing contiguously at the row's H2 columns) per instruction.  No registers
+      // are held across layer 1 (12 VGPRs per lane before: spilled in the 80-row variant, and a spill store made the
+      // wave wait out the hand-off latency at the top of every step); nobody reads H2 during layer 1, and barrier (1)
+      // drains the DMA (a pending LDS write on the vm counter) long after it landed.
       wave_poll(1, ep - 1);
-#pragma unroll
-      for (int u = 0; u < HXC; ++u) {
-        const int idx = tid + u * NT;
-        if (idx < SLICE_CH * (G - 1)) {
-          int pr, ch;
-          slice_addr(idx, pr, ch);
-          hx[u] = load_sc1_b128(xr, ((1 * 2 + ((ep - 1) & 1)) * G + pr) * SLICE * (int)sizeof(T) + ch * 16);
-        }
+      typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll 1
+      for (int ri = wave; ri < MC * (G - 1); ri += NW) {
+        const int pi = ri / MC, r = ri % MC;
+        const int pr = pi < cu ? pi : pi + 1;
+        if (lane < HC / VEC)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(lds + r * RS + OH2 + pr * HC), 16, lane * 16,
+                                                   ((1 * 2 + ((ep - 1) & 1)) * G + pr) * SLICE * (int)sizeof(T) + r * HC * (int)sizeof(T),
+                                                   0, 16);
       }
     }
-    uint4 xrg[XCH];
     const bool more = t + 1 < a.Tn;
     if (more) {
-#pragma unroll
-      for (int u = 0; u < XCH; ++u) {
-        const int ch = tid + u * NT;
-        xrg[u] = make_uint4(0, 0, 0, 0);
-        if (ch < nchunk) {
-          const int r = ch / cpr, cc = ch % cpr;
-          if (row0 + r < N) {
-            const u32x4 xv = ld_nt16(xg + ((size_t)(t + 1) * N + row0 + r) * KX + cc * VEC);
-            xrg[u] = make_uint4(xv[0], xv[1], xv[2], xv[3]);
-          }
-        }
-      }
+      // x_{t+1} -> the X buffer this step does not read, by LDS-DMA as well (one 128-byte row per instruction,
+      // non-temporal: read once)
+      typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll 1
+      for (int r = wave; r < MC; r += NW)
+        if (row0 + r < N && lane < cpr)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(lds + r * RS + (p ? OX0 : OX1)), 16, lane * 16,
+                                                   (int)((((size_t)(t + 1) * N + row0 + r) * KX) * sizeof(T)), 0, 2);
     }
     constexpr bool PR = MT <= 2;                                   // prime the next weight segment across sync points
     typename Frag<T>::type pre[DEPTH - 1][2];
@@ -333,12 +383,13 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + (p ? OX1 : OX0), 0, NKX, 0, nk1, wr1, 0, ublk, lane);
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, NKX, nk1, wr1, 0, ublk, lane);
+      FT(0)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float iv = sigmoid_f(acc[0][mt][j] + b1[0]);
-          const float gv = tanh_f(acc[1][mt][j] + b1[2]);
+          const float iv = sigmoid_f(acc[0][mt][j] + bias(0, 0));
+          const float gv = tanh_f(acc[1][mt][j] + bias(0, 2));
           ig[mt][j] = iv * gv;
           if (TRAIN) { iv1[mt][j] = iv; gv1[mt][j] = gv; }
         }
@@ -350,12 +401,13 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + (p ? OX1 : OX0), 0, NKX, 0, nk1, wr1, 1, ublk, lane);
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, NKX, nk1, wr1, 1, ublk, lane);
+      FT(1)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float fv = sigmoid_f(acc[0][mt][j] + b1[1]);
-          const float ov = sigmoid_f(acc[1][mt][j] + b1[3]);
+          const float fv = sigmoid_f(acc[0][mt][j] + bias(0, 1));
+          const float ov = sigmoid_f(acc[1][mt][j] + bias(0, 3));
           const float cn = fv * c1[mt][j] + ig[mt][j];
           c1[mt][j] = cn;
           hn1[mt][j] = ov * tanh_f(cn);
@@ -369,36 +421,16 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         }
     }
     if (PR) coop_prime<T, DEPTH>(pre, NKH, NKH, nk2, wr2, 0, ublk, lane);       // layer 2, pair (i,g), h2 half
-    // the partners' h2_{t-1} (fetched at the top of the step) -> LDS; nobody reads H2 during layer 1
-    if (t > 0) {
-#pragma unroll
-      for (int u = 0; u < HXC; ++u) {
-        const int idx = tid + u * NT;
-        if (idx < SLICE_CH * (G - 1)) {
-          int pr, ch;
-          slice_addr(idx, pr, ch);
-          const int r = ch / (HC / VEC), cc = ch % (HC / VEC);
-          *reinterpret_cast<u32x4*>(lds + r * RS + OH2 + pr * HC + cc * VEC) = hx[u];
-        }
-      }
-    }
     __syncthreads();                                              // (1) all waves done reading h1_{t-1} and x_t
+    FT(2)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) hw_lane[OH1 + (16 * mt + j) * RS] = from_f32<T>(hn1[mt][j]);
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < XCH; ++u) {
-        const int ch = tid + u * NT;
-        if (ch < nchunk) {
-          const int r = ch / cpr, cc = ch % cpr;
-          *reinterpret_cast<uint4*>(lds + r * RS + (p ? OX0 : OX1) + cc * VEC) = xrg[u];
-        }
-      }
-    }
-    __syncthreads();                                              // (2a) own h1_t slice complete in LDS
+    __syncthreads();                                              // (2a) own h1_t slice complete in LDS (drains the x DMA too)
+    FT(3)
     publish(0, OH1, ep);
+    FT(4)
 #ifndef CF_NO_SAVE
     if (TRAIN) flush_state(h1o, c1o, sc1, OH1, t);                // after the hand-off drain, not in front of it
 #endif
@@ -411,16 +443,19 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH, PR>(acc, a_lane + OH2, 0, NKH, NKH, nk2, wr2, 0, ublk, lane, pre);
+      FT(5)
       if (PR) coop_prime<T, DEPTH>(pre, NKH, 0, nk2, wr2, 0, ublk, lane);       // h1 half: in flight during the hand-off
       consume(0, OH1, ep);
       __syncthreads();                                            // (2c) full h1_t in LDS
+      FT(6)
       coop_gemm<T, MT, RS, DEPTH, PR>(acc, a_lane + OH1, 0, NKH, 0, nk2, wr2, 0, ublk, lane, pre);
+      FT(7)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float iv = sigmoid_f(acc[0][mt][j] + b2[0]);
-          const float gv = tanh_f(acc[1][mt][j] + b2[2]);
+          const float iv = sigmoid_f(acc[0][mt][j] + bias(1, 0));
+          const float gv = tanh_f(acc[1][mt][j] + bias(1, 2));
           ig2[mt][j] = iv * gv;
           if (TRAIN) { iv2[mt][j] = iv; gv2[mt][j] = gv; }
         }
@@ -432,12 +467,13 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, 2 * NKH, 0, nk2, wr2, 1, ublk, lane);
+      FT(9)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float fv = sigmoid_f(acc[0][mt][j] + b2[1]);
-          const float ov = sigmoid_f(acc[1][mt][j] + b2[3]);
+          const float fv = sigmoid_f(acc[0][mt][j] + bias(1, 1));
+          const float ov = sigmoid_f(acc[1][mt][j] + bias(1, 3));
           const float cn = fv * c2[mt][j] + ig2[mt][j];
           c2[mt][j] = cn;
           hn2[mt][j] = ov * tanh_f(cn);
@@ -453,16 +489,23 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         }
     }
     __syncthreads();                                              // (3) all waves done reading h2_{t-1} / h1_t
+    FT(10)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) hw_lane[OH2 + (16 * mt + j) * RS] = from_f32<T>(hn2[mt][j]);
     __syncthreads();                                              // own h2_t slice complete in LDS
+    FT(11)
     if (more) publish(1, OH2, ep);
+    FT(12)
 #ifndef CF_NO_SAVE
     flush_state(h2o, c2o, sc2, OH2, t);                           // inference: h2 only (the head reads it)
 #endif
   }
+#ifdef CF_STAMP
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 13; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * 2 * G + 4))[i] = ft_acc[i];
+#endif
 }
 
 // =====================================================================================================
@@ -1118,7 +1161,8 @@ template <typename T, int G, int MT, bool TRAIN>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
   constexpr int RS = 2 * KX + 2 * H + 16 / (int)sizeof(T);
-  size_t smem = (size_t)MC * RS * sizeof(T) + (TRAIN ? (size_t)2 * MC * (H / G) * sizeof(T) : 0);
+  size_t smem = (size_t)MC * RS * sizeof(T) + (TRAIN ? (size_t)2 * MC * (H / G) * sizeof(T) : 0) +
+                (MT > 3 ? (size_t)8 * (H / G) * sizeof(float) : 0);
   if (smem < 84 * 1024) smem = 84 * 1024;            // > half a CU's LDS: at most one workgroup per CU
   if (smem > 160 * 1024) return NPPC_EUNSUPPORTED;
   const long need = (long)a.clusters * 2 * 2 * G * MC * (H / G) * sizeof(T);
