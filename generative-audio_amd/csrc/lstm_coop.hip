@@ -401,6 +401,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + (p ? OX1 : OX0), 0, NKX, 0, nk1, wr1, 1, ublk, lane);
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, NKX, nk1, wr1, 1, ublk, lane);
+      // every vector-memory operation issued so far has completed here anyway (the ring just consumed its last, youngest
+      // fragment and vmcnt retires in order): make the completion of this step's LDS-DMA transfers (partner h2, next x)
+      // explicit before the barriers that publish them to the other waves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       FT(1)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
