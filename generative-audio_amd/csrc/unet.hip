@@ -709,6 +709,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// rows per workgroup of the BatchNorm column reductions: every workgroup ends with 2*C fp64 atomics on the same
+// addresses, so few large workgroups (about two per CU) beat many small ones (2000 workgroups: the atomics serialise)
+static inline int bn_rows_per_block(long P) {
+  long r = (P + 511) / 512;
+  r = (r + 255) / 256 * 256;
+  return (int)(r < 1024 ? 1024 : r);
+}
+
 static inline int grid_for(long total, int cap = 4096) {
   long g = (total + 255) / 256;
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -773,7 +781,7 @@ int nppc_conv_pack(int prec, const float* w, void* wf, void* wb, int Cout, int C
 
 int nppc_bn_stats(int prec, const void* X, long ld, long P, int C, double* st, void* stream) {
   if (!X || !st || C <= 0 || C % 8 || C / 8 > 256) return NPPC_EBADARG;
-  const int rpb = 1024;
+  const int rpb = bn_rows_per_block(P);
   LAUNCH_T(prec, bn_stats_kernel, dim3(ceil_div(P, rpb)), (const TT*)X, ld, P, C, rpb, st);
   return NPPC_OK;
 }
@@ -802,7 +810,7 @@ int nppc_bn_bwd(int prec, const void* dyA, long ldA, const void* dyB, long ldB, 
   if (!dyA || !Y || !X || !ss || !S || !dX || !dgamma || !dbeta || C % 8 || C / 8 > 256) return NPPC_EBADARG;
   const long P = (long)B * (H + 2) * (W + 2);
   if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
-  const int rpb = 1024;
+  const int rpb = bn_rows_per_block(P);
   const double n = (double)B * H * W;
   if (hipMemsetAsync(S, 0, sizeof(double) * 2 * C, (hipStream_t)stream) != hipSuccess) return NPPC_ELAUNCH;
   LAUNCH_T(prec, bn_bwd_reduce_kernel, dim3(ceil_div(P, rpb)), (const TT*)dyA, ldA, (const TT*)dyB, ldB, (const TT*)Y, ldy,

@@ -140,7 +140,7 @@ class UNetEngine:
             self.lv.append((h, w))
             h, w = h // 2, w // 2
         self.P = [B * (h + 2) * (w + 2) for h, w in self.lv]
-        self.ksplit = [int(min(256, max(1, p // 1024))) for p in self.P]
+        self.ksplit = [int(min(64, max(1, p // 1024))) for p in self.P]   # 64 slices x 9 taps already fill the chip; more only costs reduction traffic
         self.ksplit = [k // 8 * 8 if k >= 8 else k for k in self.ksplit]     # multiples of 8: XCD-aware tile order
         self.slab = None
         self.st = torch.zeros(2 * 1024, dtype=torch.float64, device=self.dev)
