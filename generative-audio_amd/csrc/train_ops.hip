@@ -93,42 +93,48 @@ constexpr int HB_ROWS = 64;
 template <typename T>
 __global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __restrict__ h2, float* __restrict__ dWh,
                                   float* __restrict__ dbh, long Nseq, int Tn, int la, int Hd, int O, int Fo) {
+  // one workgroup = frame t and every gridDim.x-th chunk of 64 sequences: the O*Hd partial sums stay in registers over
+  // all its chunks and reach memory with ONE atomic each (one workgroup per chunk meant 16k workgroups x 3840 atomics on
+  // the same 3840 addresses)
   __shared__ float dy[HB_ROWS][33];
   const int t = la + blockIdx.y;
-  const long n0 = (long)blockIdx.x * HB_ROWS;
   const int To = Tn - la;
-  for (int e = threadIdx.x; e < HB_ROWS * 32; e += blockDim.x) {
-    const int r = e / 32, o = e % 32;
-    const long nn = n0 + r;
-    float v = 0.f;
-    if (nn < Nseq && o < O) {
-      const long bo = nn / Fo, fo = nn % Fo;
-      v = dout[((bo * O + o) * Fo + fo) * To + (t - la)];
-    }
-    dy[r][o] = v;
-  }
-  __syncthreads();
   const int u = threadIdx.x;
-  if (u < Hd) {
-    float acc[32];
+  float acc[32];
 #pragma unroll
-    for (int o = 0; o < 32; ++o) acc[o] = 0.f;
-    for (int r = 0; r < HB_ROWS; ++r) {
+  for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+  float bsum = 0.f;
+  for (long n0 = (long)blockIdx.x * HB_ROWS; n0 < Nseq; n0 += (long)gridDim.x * HB_ROWS) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < HB_ROWS * 32; e += blockDim.x) {
+      const int r = e / 32, o = e % 32;
       const long nn = n0 + r;
-      if (nn >= Nseq) break;
-      const float hv = to_f32<T>(h2[((size_t)t * Nseq + nn) * Hd + u]);
-#pragma unroll
-      for (int o = 0; o < 32; ++o) acc[o] += dy[r][o] * hv;
+      float v = 0.f;
+      if (nn < Nseq && o < O) {
+        const long bo = nn / Fo, fo = nn % Fo;
+        v = dout[((bo * O + o) * Fo + fo) * To + (t - la)];
+      }
+      dy[r][o] = v;
     }
+    __syncthreads();
+    if (u < Hd) {
+      for (int r = 0; r < HB_ROWS; ++r) {
+        const long nn = n0 + r;
+        if (nn >= Nseq) break;
+        const float hv = to_f32<T>(h2[((size_t)t * Nseq + nn) * Hd + u]);
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] += dy[r][o] * hv;
+      }
+    }
+    if (threadIdx.x < 32 && threadIdx.x < O)
+      for (int r = 0; r < HB_ROWS; ++r) bsum += dy[r][threadIdx.x];
+  }
+  if (u < Hd) {
 #pragma unroll
     for (int o = 0; o < 32; ++o)
       if (o < O) atomicAdd(dWh + (size_t)o * Hd + u, acc[o]);
   }
-  if (threadIdx.x < 32 && threadIdx.x < O) {
-    float s = 0.f;
-    for (int r = 0; r < HB_ROWS; ++r) s += dy[r][threadIdx.x];
-    atomicAdd(dbh + threadIdx.x, s);
-  }
+  if (threadIdx.x < 32 && threadIdx.x < O) atomicAdd(dbh + threadIdx.x, bsum);
 }
 
 // ---------------------------------------------------------------- sub-band staging backward
@@ -289,7 +295,8 @@ int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h
   if (!dout || !whT || !h2 || !dh2 || !dWh || !dbh || O > 32 || O < 1 || Nseq % Fo) return NPPC_EBADARG;
   hipStream_t s = (hipStream_t)stream;
   const long tiles = ((Nseq + 15) / 16) * Tn;
-  dim3 gw(ceil_div(Nseq, HB_ROWS), Tn - la);
+  const int chunks = ceil_div(Nseq, HB_ROWS);
+  dim3 gw(chunks < 4 ? chunks : 4, Tn - la);
   const int bw = round_up(Hd, 64);
   if (prec == NPPC_PREC_BF16) {
     hipLaunchKernelGGL(head_bwd_dh_kernel<bf16_t>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const bf16_t*)whT,
