@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int RPB = 32;   // frames per workgroup
+constexpr int RPB = 64;   // frames per workgroup (each workgroup ends with per-channel atomics: fewer, larger workgroups)
 
 struct GnCtx {
   float mean, rstd;
