@@ -176,3 +176,38 @@ def test_two_optimizer_steps_through_the_trainer(name, opt, tmp_path):
             assert (d > lim).mean() <= (0.05 if loose else 0.002) and np.median(d) < lim, (it, n, float(d.max()))
             checked += 1
         assert checked >= 6
+
+
+def test_training_loop_reduces_the_objective(tmp_path):
+    """30 optimisation steps of the bf16 production path on one synthetic minibatch (full-size nets, lambda at its
+    start value): the objective must fall and stay finite -- exercises workspace / flag / stream reuse across steps."""
+    from nppc_audio import ops_lstm
+    from nppc_audio.data import SyntheticNoisySpeech
+    from nppc_audio.fullsubnet import FullSubNet_Plus, FullSubNetPlusConfig
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    torch.manual_seed(0)
+    ck = os.path.join(str(tmp_path), "restorer.tar")
+    torch.save({"model": FullSubNet_Plus(FullSubNetPlusConfig()).state_dict()}, ck)
+    Bq, Lq = 8, 16000
+    cfg = NPPCAudioTrainerConfig(
+        nppc_model_configuration=dict(
+            pretrained_restoration_model_configuration=dict(num_groups_in_drop_band=1), pretrained_restoration_model_path=ck,
+            audio_pc_wrapper_configuration=dict(multi_direction_configuration=dict(num_groups_in_drop_band=2, n_directions=3)),
+            stft_configuration=dict(nfft=512, hop_length=256, win_length=512), device="cuda"),
+        data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+        data_loader_configuration=dict(batch_size=Bq, num_workers=0, pin_memory=False, shuffle=False),
+        optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
+        device="cuda")
+    ds = SyntheticNoisySpeech(Bq, Lq)
+    tr = NPPCAudioTrainer(cfg, dataset=ds)
+    clips = [ds[i] for i in range(Bq)]
+    batch = (torch.stack([c[0] for c in clips]).cuda(), torch.stack([c[1] for c in clips]).cuda())
+    objs = []
+    for _ in range(30):
+        _, obj, log = tr.train_step(batch)
+        objs.append(float(obj))
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert all(np.isfinite(objs)) and tr.step == 30
+    assert objs[-1] < objs[0] - 0.02, objs[::5]
+    assert float(log["reconst_err"].mean()) < 1.0
