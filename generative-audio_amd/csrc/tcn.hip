@@ -6,6 +6,7 @@
 // ld = channels rounded up to 64, padding zero) so every 1x1 conv / Linear is one row-major NT GEMM
 //   Y[R][N] = X[R][K] * W[N][K]^T,  R = B*Tp
 // on bf16 (or exact-f32) MFMA 16x16 tiles, with bias / PReLU / GroupNorm statistics / residual fused in the epilogue.
+#include <cstdlib>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -658,14 +659,16 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+// BM = 128 (4 waves, two workgroups per CU) or 256 (8 waves, one per CU: 0.75x the operand bytes per FLOP through the
+// CU's 64 B/clk global-load path, which is what bounds the 128 x 128 tile)
+template <int BN, int BM = 128>
+__global__ __launch_bounds__(2 * BM, BM == 128 ? 2 : 1) void gemm_tn_tiled_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                long ldb, float* __restrict__ C, long ldc, long slab_stride,
                                                                long Rz, int ntap, int Wp, int shift_a, int nzb, long bsA,
                                                                long bsB, long bsC) {
-  constexpr int BM = 128, BR = 64;
+  constexpr int BR = 64, NT = 2 * BM;
   constexpr int RSA = BM + 8, RSB = BN + 8;                 // LDS row strides (elements): 16-byte aligned rows
-  constexpr int WN = BN / 2;                                // columns per wave (2x2 waves)
+  constexpr int WN = BN / 2;                                // columns per wave (BM/64 x 2 waves)
   constexpr int NJ = WN / 16;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][BR * RSA + BR * RSB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, qq = lane >> 4;
@@ -701,22 +704,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
 
   // staging: A tile 64 rows x 16 chunks (16 B) = 1024 chunks -> 4 per thread; B tile 64 x BN/8 chunks
   constexpr int ACH = BM / 8, BCH = BN / 8;
-  constexpr int NA = BR * ACH / 256, NB = BR * BCH / 256;
-  static_assert(NA == 4 && (NB == 4 || NB == 2), "staging slots are named registers");
+  constexpr int NA = BR * ACH / NT, NB = BR * BCH / NT;
+  static_assert(NA == 4 && (NB == 4 || NB == 2 || NB == 1), "staging slots are named registers");
   // chunk (row, c) of slot i: idx = tid + 256*i.  A: row = idx/16 -> rows (tid>>4) + 16*i, c = tid & 15.
   const int arow = tid / ACH, ac = tid % ACH, brow = tid / BCH, bc = tid % BCH;
-  constexpr int ASTEP = 256 / ACH, BSTEP = 256 / BCH;                                    // rows between slots
+  constexpr int ASTEP = NT / ACH, BSTEP = NT / BCH;                                      // rows between slots
   const bf16_t* gA = Ab + (long)arow * lda + ac * 8;
   const bf16_t* gB = Bb + (long)brow * ldb + bc * 8;
   const int sA = arow * RSA + ac * 8, sB = BR * RSA + brow * RSB + bc * 8;
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = {}, rb3 = {};
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1 = {}, rb2 = {}, rb3 = {};
 #define TN_GLOAD(r0)                                                            \
   ra0 = *reinterpret_cast<const uint4*>(gA + ((r0) + 0 * ASTEP) * lda);         \
   ra1 = *reinterpret_cast<const uint4*>(gA + ((r0) + 1 * ASTEP) * lda);         \
   ra2 = *reinterpret_cast<const uint4*>(gA + ((r0) + 2 * ASTEP) * lda);         \
   ra3 = *reinterpret_cast<const uint4*>(gA + ((r0) + 3 * ASTEP) * lda);         \
   rb0 = *reinterpret_cast<const uint4*>(gB + ((r0) + 0 * BSTEP) * ldb);         \
-  rb1 = *reinterpret_cast<const uint4*>(gB + ((r0) + 1 * BSTEP) * ldb);         \
+  if (NB >= 2) rb1 = *reinterpret_cast<const uint4*>(gB + ((r0) + 1 * BSTEP) * ldb); \
   if (NB == 4) {                                                                \
     rb2 = *reinterpret_cast<const uint4*>(gB + ((r0) + 2 * BSTEP) * ldb);       \
     rb3 = *reinterpret_cast<const uint4*>(gB + ((r0) + 3 * BSTEP) * ldb);       \
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
   *reinterpret_cast<uint4*>(&lds[buf][sA + 2 * ASTEP * RSA]) = ra2;             \
   *reinterpret_cast<uint4*>(&lds[buf][sA + 3 * ASTEP * RSA]) = ra3;             \
   *reinterpret_cast<uint4*>(&lds[buf][sB + 0 * BSTEP * RSB]) = rb0;             \
-  *reinterpret_cast<uint4*>(&lds[buf][sB + 1 * BSTEP * RSB]) = rb1;             \
+  if (NB >= 2) *reinterpret_cast<uint4*>(&lds[buf][sB + 1 * BSTEP * RSB]) = rb1; \
   if (NB == 4) {                                                                \
     *reinterpret_cast<uint4*>(&lds[buf][sB + 2 * BSTEP * RSB]) = rb2;           \
     *reinterpret_cast<uint4*>(&lds[buf][sB + 3 * BSTEP * RSB]) = rb3;           \
@@ -791,12 +794,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tiled_kernel(const bf16_t* __r
 
 // C_slab[z] [M][N] = A[rows slice z][M]^T * B[rows slice z][N]  (bf16 operands, fp32 slabs).  M % 128 == 0,
 // N % 64 == 0, R % (64*ksplit) == 0, lda/ldb multiples of 8.
+// 256-row tiles are on unless NPPC_TN_BIG=0 (A/B switch for tools/bench_tn.py)
+static bool tn_big_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NPPC_TN_BIG");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                      int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0) {
+  // 256-row tiles (+4...11 % at these shapes) only when they still give every CU a few workgroups
+  if (N % 128 == 0 && M % 256 == 0 && tn_big_tiles() && (long)(M / 256) * (N / 128) * ksplit * ntap * batch >= 1024) {
+    dim3 grid(M / 256, N / 128, ksplit * ntap * batch);
+    hipLaunchKernelGGL((gemm_tn_tiled_kernel<128, 256>), grid, dim3(512), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+                       ldc, (long)M * ldc, R / ksplit, ntap, Wp, shift_a, ksplit * ntap, sA, sB, sC);
+  } else if (N % 128 == 0) {
     dim3 grid(M / 128, N / 128, ksplit * ntap * batch);
     hipLaunchKernelGGL(gemm_tn_tiled_kernel<128>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc,
                        (long)M * ldc, R / ksplit, ntap, Wp, shift_a, ksplit * ntap, sA, sB, sC);
