@@ -307,6 +307,123 @@ __global__ __launch_bounds__(256) void mix_snr_kernel(const float* __restrict__ 
     }
 }
 
+// ---- inpainting batch synthesis (dataset/audio_dataset_inpainting.py) -------------------------------------------------
+// :154-168 _normalize_audio (rms + 1e-8 inside the log), :170-181 the gap mask (zeros on [g0, g1)), :223-251
+// time_to_spec_mask for that gap: frame t is 1 iff its clamped window [t*hop - win/2, +win) misses the gap (an empty
+// window gives 0).  One workgroup per clip; fp64 sum of squares; two passes over the clip.
+__global__ __launch_bounds__(256) void inpaint_prepare_kernel(const float* __restrict__ clean, const int* __restrict__ g0s,
+                                                              const int* __restrict__ g1s, int do_norm, float target_dbfs,
+                                                              float* __restrict__ clean_out, float* __restrict__ masked_out,
+                                                              float* __restrict__ mask_frames, int L, int win, int hop,
+                                                              int T) {
+  __shared__ double red[4];
+  __shared__ float bc;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* c = clean + (size_t)b * L;
+  float gain = 1.f;
+  if (do_norm) {
+    double sc = 0.0;
+    for (int i = tid; i < L; i += 256) sc += (double)c[i] * (double)c[i];
+    sc = wave_sum(sc);
+    if (lane == 0) red[wave] = sc;
+    __syncthreads();
+    if (tid == 0) {
+      const float rms = (float)sqrt((red[0] + red[1] + red[2] + red[3]) / L);
+      bc = powf(10.f, (target_dbfs - 20.f * log10f(rms + 1e-8f)) / 20.f);
+    }
+    __syncthreads();
+    gain = bc;
+  }
+  int g0 = g0s[b], g1 = g1s[b];
+  g0 = g0 < 0 ? 0 : g0;                                      // python slice clamping of mask[:, start:end]
+  g1 = g1 > L ? L : g1;
+  for (int i = tid; i < L; i += 256) {
+    const float v = c[i] * gain;
+    if (clean_out) clean_out[(size_t)b * L + i] = v;
+    if (masked_out) masked_out[(size_t)b * L + i] = (i >= g0 && i < g1) ? 0.f : v;
+  }
+  for (int t = tid; t < T; t += 256) {
+    int s = t * hop - win / 2, e = s + win;
+    s = s < 0 ? 0 : s;
+    e = e > L ? L : e;
+    float m = 0.f;
+    if (e > s) m = (g1 > g0 && g0 < e && g1 > s) ? 0.f : 1.f;
+    mask_frames[(size_t)b * T + t] = m;
+  }
+}
+
+// time_to_spec_mask for an ARBITRARY sample mask [B, L] (:223-251): one wave per frame, (min over the window) == 1
+__global__ __launch_bounds__(256) void time_to_spec_mask_kernel(const float* __restrict__ mask_time, float* __restrict__ out,
+                                                                int L, int win, int hop, int center, int T, int B) {
+  const int lane = threadIdx.x & 63;
+  const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= (long)B * T) return;
+  const int b = (int)(f / T), t = (int)(f % T);
+  int s = t * hop - (center ? win / 2 : 0), e = s + win;
+  s = s < 0 ? 0 : s;
+  e = e > L ? L : e;
+  int ok = 1;
+  for (int i = s + lane; i < e; i += 64) ok &= mask_time[(size_t)b * L + i] == 1.f;
+  ok = __all(ok);
+  if (lane == 0) out[f] = (e > s && ok) ? 1.f : 0.f;
+}
+
+// utils.audio_to_stft (utils.py:150-175) for ANY nfft = win_length <= 512 (the inpainting configuration is 255 / hop 128):
+// centred (reflect-padded) periodic-hann STFT written as the [B, 2, F, T] real/imag pair, plus (optionally) the
+// frame-masked copy stft_clean * mask (audio_dataset_inpainting.py:307-310).  Direct DFT: 32 frames per workgroup in LDS,
+// exact twiddles exp(-2 pi i (f n mod N) / N) from a table built in double, fp64 accumulation.
+constexpr int DFT_FR = 32;
+__global__ __launch_bounds__(256) void stft_dft_kernel(const float* __restrict__ wave, const float* __restrict__ mask_frames,
+                                                       float* __restrict__ spec, float* __restrict__ masked, int L, int N,
+                                                       int hop, int T) {
+  extern __shared__ double dsm[];
+  const int F = N / 2 + 1, RS = N | 1;                       // odd row stride: lanes = frames hit distinct banks
+  double* twc = dsm;
+  double* tws = dsm + N;
+  float* fr = reinterpret_cast<float*>(dsm + 2 * N);         // [DFT_FR][RS] windowed frames
+  const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * DFT_FR;
+  for (int i = tid; i < N; i += 256) {
+    double sn, cs;
+    sincospi(-2.0 * i / N, &sn, &cs);
+    twc[i] = cs;
+    tws[i] = sn;
+  }
+  const float* wv = wave + (size_t)b * L;
+  for (int e = tid; e < DFT_FR * N; e += 256) {
+    const int j = e / N, n = e % N, t = t0 + j;
+    float v = 0.f;
+    if (t < T) {
+      int sidx = t * hop + n - N / 2;
+      if (sidx < 0) sidx = -sidx;
+      if (sidx >= L) sidx = 2 * (L - 1) - sidx;
+      v = wv[sidx] * (float)(0.5 - 0.5 * cospi(2.0 * n / N));
+    }
+    fr[j * RS + n] = v;
+  }
+  __syncthreads();
+  const int j = tid & (DFT_FR - 1), t = t0 + j;
+  if (t >= T) return;
+  const float mk = mask_frames ? mask_frames[(size_t)b * T + t] : 1.f;
+  for (int f = tid / DFT_FR; f < F; f += 256 / DFT_FR) {
+    double re = 0.0, im = 0.0;
+    int idx = 0;
+    for (int n = 0; n < N; ++n) {
+      const double x = (double)fr[j * RS + n];
+      re += x * twc[idx];
+      im += x * tws[idx];
+      idx += f;
+      if (idx >= N) idx -= N;
+    }
+    const size_t o = (((size_t)b * 2) * F + f) * T + t, oi = o + (size_t)F * T;
+    spec[o] = (float)re;
+    spec[oi] = (float)im;
+    if (masked) {
+      masked[o] = (float)re * mk;
+      masked[oi] = (float)im * mk;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -385,6 +502,39 @@ int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, fl
   if (!clean || !noise || !snr_db || !noisy_out || !clean_out || B <= 0 || L <= 0) return NPPC_EBADARG;
   hipLaunchKernelGGL(mix_snr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, noise, snr_db, target_dbfs, noisy_out,
                      clean_out, L);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_inpaint_prepare(const float* clean, const int* gap_start, const int* gap_end, int do_norm, float target_dbfs,
+                         float* clean_out, float* masked_out, float* mask_frames, int B, int L, int win, int hop, int T,
+                         void* stream) {
+  if (!clean || !gap_start || !gap_end || !mask_frames || B <= 0 || L <= 0 || win <= 0 || hop <= 0 || T <= 0)
+    return NPPC_EBADARG;
+  hipLaunchKernelGGL(inpaint_prepare_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, gap_start, gap_end, do_norm,
+                     target_dbfs, clean_out, masked_out, mask_frames, L, win, hop, T);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_time_to_spec_mask(const float* mask_time, float* mask_frames, int B, int L, int win, int hop, int center, int T,
+                           void* stream) {
+  if (!mask_time || !mask_frames || B <= 0 || L <= 0 || win <= 0 || hop <= 0 || T <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(time_to_spec_mask_kernel, dim3(ceil_div((long)B * T, 4L)), dim3(256), 0, (hipStream_t)stream, mask_time,
+                     mask_frames, L, win, hop, center, T, B);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_stft_pair(const float* wave, const float* mask_frames, float* spec, float* masked_spec, int B, int L, int nfft,
+                   int hop, void* stream) {
+  if (!wave || !spec || B <= 0 || L <= nfft / 2 || hop <= 0 || nfft < 2) return NPPC_EBADARG;
+  if (nfft > 512) return NPPC_EUNSUPPORTED;
+  if (masked_spec && !mask_frames) return NPPC_EBADARG;
+  const int T = 1 + L / hop;
+  const size_t lds = 2 * sizeof(double) * nfft + sizeof(float) * DFT_FR * (nfft | 1);
+  hipLaunchKernelGGL(stft_dft_kernel, dim3(ceil_div(T, DFT_FR), B), dim3(256), lds, (hipStream_t)stream, wave, mask_frames,
+                     spec, masked_spec, L, nfft, hop, T);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -115,6 +115,9 @@ SIGS = {
     "nppc_adam_step": [P, P, P, P, L, D, D, D, D, D, I, D, P],
     "nppc_loss_solve_eps": [P, P, P, P, P, P, P, P, P, P, I, I, D, I, P],
     "nppc_mix_snr": [P, P, P, F, P, P, I, I, P],
+    "nppc_inpaint_prepare": [P, P, P, I, F, P, P, P, I, I, I, I, I, P],
+    "nppc_time_to_spec_mask": [P, P, I, I, I, I, I, I, P],
+    "nppc_stft_pair": [P, P, P, P, I, I, I, I, P],
     "nppc_sumsq": [P, L, P, P],
     "nppc_adam_step_clip": [P, P, P, P, L, D, D, D, D, D, I, D, P, D, P],
     "nppc_logmag": [P, P, L, I, L, P, P],

@@ -176,6 +176,21 @@ int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double 
 int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, float* noisy_out,
                  float* clean_out, int B, int L, void* stream);
 
+/* inpainting batch synthesis (dataset/audio_dataset_inpainting.py __getitem__ :291-313), one launch per batch:
+ * _normalize_audio (:154-168, when do_norm), the gap mask of _create_random_mask (:170-181: zeros on
+ * [gap_start[b], gap_end[b])) applied to the audio (masked_out, nullable), and time_to_spec_mask (:223-251, centred)
+ * for that gap -> mask_frames [B, T]. */
+int nppc_inpaint_prepare(const float* clean, const int* gap_start, const int* gap_end, int do_norm, float target_dbfs,
+                         float* clean_out /*nullable*/, float* masked_out /*nullable*/, float* mask_frames, int B, int L,
+                         int win, int hop, int T, void* stream);
+/* time_to_spec_mask (:223-251) for an arbitrary sample mask [B, L]: frame = 1 iff every sample of its clamped window is 1 */
+int nppc_time_to_spec_mask(const float* mask_time, float* mask_frames, int B, int L, int win, int hop, int center, int T,
+                           void* stream);
+/* utils.audio_to_stft (utils.py:150-175) for any nfft = win_length <= 512: [B, L] -> spec [B, 2, F, T] (T = 1 + L / hop);
+ * masked_spec (nullable) = spec * mask_frames[b, t] (audio_dataset_inpainting.py:307-310) */
+int nppc_stft_pair(const float* wave, const float* mask_frames /*nullable*/, float* spec, float* masked_spec /*nullable*/,
+                   int B, int L, int nfft, int hop, void* stream);
+
 /* clip_grad_norm_(max_norm) + Adam without a host round trip (inpainting/trainer/nppc_trainer.py:149-154):
  * nppc_sumsq accumulates sum(g^2) into a zeroed device double, nppc_adam_step_clip reads it. */
 int nppc_sumsq(const float* g, long n, double* out, void* stream);

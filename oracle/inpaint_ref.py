@@ -178,3 +178,47 @@ def adam_step(params, grads, state, t, lr=1e-4, b1=0.5, b2=0.999, eps=1e-8):
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
         p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+
+
+# ---- batch synthesis for the inpainting step (second half) ----------------------------
+def normalize_dbfs(wave, target_db=-25.0):
+    """AudioInpaintingDataset._normalize_audio (dataset/audio_dataset_inpainting.py:154-168), fixed target:
+    rms over the whole clip, gain = 10 ** ((target - 20 log10(rms + 1e-8)) / 20)."""
+    rms = wave.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    return wave * 10 ** ((target_db - 20 * torch.log10(rms + 1e-8)) / 20)
+
+
+def gap_mask(length, start, end):
+    """_create_random_mask with a given start (audio_dataset_inpainting.py:170-181): ones, zeros on [start, end)."""
+    m = torch.ones(1, length)
+    m[:, start:end] = 0
+    return m
+
+
+def time_to_spec_mask(mask_time, n_frames, length, win, hop, center=True):
+    """time_to_spec_mask (audio_dataset_inpainting.py:223-251): frame t is 1 iff every sample of its (clamped)
+    window [t*hop - win//2, +win) is 1; an empty window gives 0."""
+    out = torch.zeros(n_frames)
+    for t in range(n_frames):
+        s = t * hop - (win // 2 if center else 0)
+        e = min(s + win, length)
+        s = max(s, 0)
+        out[t] = 0.0 if e <= s else float(bool(mask_time[0, s:e].min() == 1))
+    return out
+
+
+def stft_pair(wave, nfft, hop, win):
+    """utils.audio_to_stft (utils.py:150-175): centred hann STFT -> [B,2,F,T]."""
+    s = torch.stft(wave, nfft, hop, win, window=torch.hann_window(win, dtype=wave.dtype), center=True, return_complex=True)
+    return torch.stack((s.real, s.imag), dim=1)
+
+
+def inpaint_sample(clean, start, end, nfft=255, hop=128, win=255):
+    """__getitem__ after the crop (audio_dataset_inpainting.py:291-313) for one clip [1,L]:
+    -> (stft_masked[2,F,T], mask_frames[T], stft_clean[2,F,T], masked_audio[1,L]); the masking is applied to the
+    SPECTROGRAM frames (stft_clean * mask), not by transforming the masked audio."""
+    L = clean.shape[1]
+    mask = gap_mask(L, start, end).to(clean.dtype)
+    spec = stft_pair(clean, nfft, hop, win)
+    mf = time_to_spec_mask(mask, spec.shape[3], L, win, hop).to(clean.dtype)
+    return (spec * mf[None, None, None, :])[0], mf, spec[0], clean * mask

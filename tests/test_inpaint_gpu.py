@@ -333,3 +333,73 @@ def test_two_clipped_optimizer_steps(name, opt, tmp_path):
             assert (d > 0.05 * 1e-4 * it + 1e-7).sum() <= max(1, 1e-2 * d.size) and np.median(d) < 2e-6, (it, n)
             checked += 1
         assert checked >= 8
+
+
+# ---- row f3 (second half): on-device batch synthesis of the inpainting step -------------------------------------------
+@pytest.mark.parametrize("name", ["c3", "tiny"])
+def test_batch_synthesis_against_reference_dataset_goldens(name):
+    """normalise -> gap mask -> centred STFT (nfft 255 / 63: not powers of two) -> time_to_spec_mask -> masked STFT,
+    against the outputs of the reference's own dataset methods (tests/golden/inp_data.npz)."""
+    from nppc_audio.inpainting.data import inpainting_batch_on_device
+    z = np.load(os.path.join(GOLD, "inp_data.npz"))
+    nfft, hop, L = (int(v) for v in z[f"{name}_cfg"])
+    gaps = z[f"{name}_gaps"]
+    clean = torch.from_numpy(z[f"{name}_clean_in"]).cuda()
+    sm, mf, sc, ma = inpainting_batch_on_device(clean, gaps[:, 0], gaps[:, 0] + gaps[:, 1], nfft, hop)
+    torch.cuda.synchronize()
+    assert np.array_equal(mf.cpu().numpy(), z[f"{name}_mask_frames"])          # 0/1 values: bit exact
+    scale = np.abs(z[f"{name}_stft_clean"]).max()
+    assert np.abs(sc.cpu().numpy() - z[f"{name}_stft_clean"]).max() < 2e-6 * scale   # fp32 FFT vs fp64-accumulated DFT
+    assert np.abs(sm.cpu().numpy() - z[f"{name}_stft_masked"]).max() < 2e-6 * scale
+    gold_ma = z[f"{name}_masked_audio"]
+    got_ma = ma[:, 0].cpu().numpy()
+    assert np.array_equal(got_ma == 0, gold_ma == 0)
+    assert np.abs(got_ma - gold_ma).max() < 2e-6 * np.abs(gold_ma).max()       # gain: powf / log10f vs torch's
+    # masked frames are exactly zero in the masked STFT, untouched elsewhere
+    keep = mf.bool()[:, None, None, :].expand_as(sm)
+    assert float(sm[~keep].abs().max()) == 0.0 and torch.equal(sm[keep], sc[keep])
+
+
+def test_time_to_spec_mask_arbitrary_masks_and_stft_against_oracle():
+    from nppc_audio.inpainting.data import audio_to_stft, time_to_spec_mask
+    g = torch.Generator().manual_seed(5)
+    for (win, hop, L, center) in ((255, 128, 4000, True), (63, 32, 777, True), (64, 16, 500, False), (255, 128, 130, True)):
+        T = 1 + L // hop
+        m = torch.ones(5, L)
+        m[0, 0] = 0
+        m[1, L - 1] = 0
+        m[2, torch.randint(0, L, (7,), generator=g)] = 0
+        m[3, :] = 0
+        got = time_to_spec_mask(m.cuda(), T + 2, L, win, hop, center).cpu()      # T + 2: frames whose window is empty
+        for b in range(5):
+            want = R.time_to_spec_mask(m[b:b + 1], T + 2, L, win, hop, center)
+            assert torch.equal(got[b], want), (win, hop, L, center, b)
+    # the general-N STFT against torch.stft on the CPU, several sizes (odd, even, power of two)
+    for nfft, hop, L in ((255, 128, 3000), (63, 32, 500), (100, 25, 1000), (512, 256, 4096), (254, 127, 128)):
+        x = torch.randn(3, L, generator=g)
+        want = R.stft_pair(x.double(), nfft, hop, nfft)
+        got = audio_to_stft(x.cuda(), nfft, hop).cpu().double()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-6, (nfft, hop, L)
+
+
+def test_synthesised_batch_feeds_the_train_step():
+    """the synthesised tuple drives NPPCAudioInpaintingTrainer.base_step unchanged (shapes, dtypes, value ranges)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import bench_inpainting as bi
+    from nppc_audio.inpainting.data import inpainting_batch_on_device
+    B, L = 4, 8000
+    _, clean = W.synth_batch(B, L)
+    sm, mf, sc, ma = inpainting_batch_on_device(torch.from_numpy(clean).cuda(), [3000, 0, 7000, 4000],
+                                                [4600, 800, 8000, 4400])
+    Fq, T = sc.shape[2], sc.shape[3]
+    assert (Fq, T) == (128, 63) and ma.shape == (B, 1, L)
+    tr = bi.build("fp32", B, Fq, T)
+    tr.step = 500
+    rec, obj, log = tr.base_step((sm, mf, sc))
+    obj.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(obj) and float(rec.min()) > -1e-4 and float(rec.max()) < 1 + 1e-4
+    w = log["w_mat"]
+    assert float(w[mf.bool()[:, None, None, :].expand_as(w)].abs().max()) == 0.0

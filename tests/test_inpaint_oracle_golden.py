@@ -145,3 +145,25 @@ def test_gram_schmidt_real_golden():
         g = flat[b] @ flat[b].T
         off = g - np.diag(np.diag(g))
         assert np.abs(off).max() < 1e-3 * np.abs(np.diag(g)).max()
+
+
+@pytest.mark.parametrize("name", ["c3", "tiny"])
+def test_batch_synthesis_oracle_matches_reference_dataset(name):
+    """row f3 (second half): the oracle's restatement of AudioInpaintingDataset's preparation against the outputs of the
+    reference's own methods (tests/golden/inp_data.npz, written by make_goldens_inpaint_data.py)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import inpaint_ref as IR
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inp_data.npz"))
+    nfft, hop, L = (int(v) for v in z[f"{name}_cfg"])
+    clean = torch.from_numpy(z[f"{name}_clean_in"])
+    for i, (g0, glen) in enumerate(z[f"{name}_gaps"]):
+        audio = IR.normalize_dbfs(clean[i:i + 1])
+        assert np.array_equal(audio[0].numpy(), z[f"{name}_norm"][i])
+        sm, mf, sc, ma = IR.inpaint_sample(audio, int(g0), int(g0 + glen), nfft, hop, nfft)
+        assert np.array_equal(mf.numpy(), z[f"{name}_mask_frames"][i])
+        assert np.array_equal(sc.numpy(), z[f"{name}_stft_clean"][i])
+        assert np.array_equal(sm.numpy(), z[f"{name}_stft_masked"][i])
+        assert np.array_equal(ma[0].numpy(), z[f"{name}_masked_audio"][i])
+        assert 0 < int((mf == 0).sum()) < mf.numel()
