@@ -118,6 +118,11 @@ SIGS = {
     "nppc_inpaint_prepare": [P, P, P, I, F, P, P, P, I, I, I, I, I, P],
     "nppc_time_to_spec_mask": [P, P, I, I, I, I, I, I, P],
     "nppc_stft_pair": [P, P, P, P, I, I, I, I, P],
+    "nppc_dropout": [I, P, L, L, I, F, L, I, P, P],
+    "nppc_pca_work_elems": [I, I, I, PL],
+    "nppc_pca_batch": [P, I, I, I, I, P, P, P, P, P, P, P],
+    "nppc_pair_loss": [P, P, P, P, P, P, P, P, P, I, I, L, D, P],
+    "nppc_pair_loss_bwd": [P, P, P, P, F, F, P, I, I, L, P],
     "nppc_sumsq": [P, L, P, P],
     "nppc_adam_step_clip": [P, P, P, P, L, D, D, D, D, D, I, D, P, D, P],
     "nppc_logmag": [P, P, L, I, L, P, P],

@@ -23,9 +23,12 @@ class UNetConfig(pydantic.BaseModel):
 
 def _double_conv(in_ch, out_ch, dropout):
     # tmp_utils.double_conv: Sequential indices 0 conv, 1 BN, 2 act, 3 conv, 4 BN, 5 act(, 6 dropout);
-    # only the parameterised entries exist here, under the same indices
+    # only the parameterised entries (and the nn.Dropout flag-holder utils.enable_dropout looks for) exist here,
+    # under the same indices
     d = nn.ModuleDict({"0": nn.Conv2d(in_ch, out_ch, 3, padding=1), "1": nn.BatchNorm2d(out_ch),
                        "3": nn.Conv2d(out_ch, out_ch, 3, padding=1), "4": nn.BatchNorm2d(out_ch)})
+    if dropout:
+        d["6"] = nn.Dropout(dropout)
     d.dropout_p = float(dropout)
     return d
 
@@ -72,6 +75,9 @@ class UNet(nn.Module):
         self.outc = _Holder(conv=nn.Conv2d(64, config.out_channels, 1))
         self._engine = None
         self.flat_grad_only = False
+        self.dropout_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF   # MC-dropout stream (Philox key)
+        self.dropout_pass = 0                                                # advanced by every stochastic forward
+        self.dropout_tap = None                                              # tests: {} collects the keep bits
 
     def _prec(self):
         return H.PREC_BF16 if self.config.precision == "bf16" else H.PREC_F32
@@ -94,17 +100,25 @@ class UNet(nn.Module):
                 return False
         return all(b.device == self._engine.dev for b in self.buffers())
 
-    def _check_dropout(self):
-        if self.training and self.config.dropout:
+    def _dropout_state(self):
+        """None, or the Philox stream of this stochastic pass when any nn.Dropout of the net is in train mode
+        (utils.enable_dropout, utils.py:334-338; restoration_model.train() in base_step2, nppc_trainer.py:268)."""
+        p = self.config.dropout
+        if not p or not any(isinstance(m, nn.Dropout) and m.training for m in self.modules()):
+            return None
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             raise NotImplementedError(
-                "UNet (MI355X build): train-mode dropout is not on the NPPC hot path (the restorer runs in eval mode, "
-                "nppc_model.py:95,113; the direction U-Net is configured with dropout 0, config_nppc.yaml:33-36)")
+                "UNet (MI355X build): dropout is implemented for MC-dropout inference (no_grad / frozen weights); the "
+                "training path configures the direction U-Net with dropout 0 (config_nppc.yaml:33-36)")
+        st = dict(p=p, seed=self.dropout_seed, pass_id=self.dropout_pass, tap=self.dropout_tap)
+        self.dropout_pass += 1
+        return st
 
     def run(self, maps, map_bstride, shape, mask, out, out_pstride, xin=None, xin_bstride=0):
         """engine entry used by the wrappers: see UNetEngine.forward"""
-        self._check_dropout()
+        drop = self._dropout_state()
         train = self.training
-        self.engine().forward(shape, maps, map_bstride, mask, out, out_pstride, xin, xin_bstride, train=train)
+        self.engine().forward(shape, maps, map_bstride, mask, out, out_pstride, xin, xin_bstride, train=train, dropout=drop)
 
     def forward(self, x):
         """[B, in_channels, F, T] -> [B, out_channels, F, T] (unet.py:277-290)"""

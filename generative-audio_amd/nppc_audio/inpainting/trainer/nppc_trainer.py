@@ -113,6 +113,35 @@ class NPPCAudioInpaintingTrainer(nn.Module):
         return inpainting_base_step(self.nppc_model, batch, self.step, self.config.second_moment_loss_grace,
                                     self.config.second_moment_loss_lambda)
 
+    def base_step2(self, batch, n_mc_samples=50):
+        """nppc_trainer.py:244-336: the alternative target -- the NPPC directions are fitted to the MC-dropout + PCA
+        components of the restorer (50 stochastic passes with the WHOLE restorer in train mode, as the reference's
+        `restoration_model.train()` does: BatchNorm uses batch statistics and its running buffers move)."""
+        from ..mc_baseline import PairProjectionLoss, calculate_unet_baseline
+        masked_spec, mask, clean_spec = batch
+        clean_norm, mask4, masked_norm = preprocess_data(clean_spec, masked_spec, mask)
+        w_mat = self.nppc_model(masked_norm, mask4)                      # [B, n_dirs, F, T]
+        restoration_model = self.nppc_model.pretrained_restoration_model
+        restoration_model.train()
+        try:
+            mc = calculate_unet_baseline(restoration_model, masked_norm, mask4, n_mc_samples=n_mc_samples,
+                                         n_components=w_mat.shape[1])
+        finally:
+            restoration_model.eval()
+        w_mc, singular_values = mc['scaled_principal_components'], mc['singular_vals']
+        lam = second_moment_weight(self.step, self.config.second_moment_loss_grace, self.config.second_moment_loss_lambda)
+        reconst_err, objective, proj, w_norms, second_moment_mse = PairProjectionLoss.apply(w_mat, w_mc, singular_values, lam)
+        log = {
+            'w_mat': w_mat.detach(),
+            'w_mc': w_mc.detach(),
+            'proj_W_mc_on_W_nppc': proj.detach(),
+            'w_norms': w_norms.detach(),
+            'reconst_err': reconst_err.detach(),
+            'second_moment_mse': second_moment_mse.detach(),
+            'objective': objective.detach(),
+        }
+        return reconst_err, objective, log
+
     def _calculate_final_objective(self, reconst_err, second_moment_mse):
         lam = second_moment_weight(self.step, self.config.second_moment_loss_grace, self.config.second_moment_loss_lambda)
         return reconst_err.mean() + lam * second_moment_mse.mean()

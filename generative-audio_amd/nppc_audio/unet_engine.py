@@ -21,6 +21,7 @@ PLAN = (("inc", "conv.conv", None, 64, 0), ("down1", "mpconv.1.conv", 64, 128, 1
         ("up2", "conv.conv", 512, 128, 2), ("up3", "conv.conv", 256, 64, 1), ("up4", "conv.conv", 128, 64, 0))
 IN_LD = 64          # the 1- or 2-channel net input is staged into a 64-wide zero-padded pixel row
 OUT_LD = 64         # so is the K-channel output of the 1x1 convolution
+DROP_BLOCKS = ("down3", "down4", "up1", "up2")    # double_convs that end in nn.Dropout (unet.py:254-257)
 
 
 PROFILE = None      # bench hook: list of (kind, algorithmic flops, start event, end event)
@@ -200,8 +201,20 @@ class UNetEngine:
         saved[blk] = dict(x=x, ldx=ldx, raw_a=raw_a, act_a=act_a, raw_b=raw_b, out=out, ldo=ldo, ss_a=ss_a, ss_b=ss_b,
                           cin=cin, cout=cout, level=level, path=path)
 
-    def forward(self, shape, maps, map_bstride, mask, out, out_pstride, xin=None, xin_bstride=0, train=False):
-        """maps: list of fp32 tensors holding [B][F*T] planes with batch stride `map_bstride` (the net's input
+    def _dropout(self, blk, x, ldx, cout, level, dropout):
+        """nn.Dropout at the end of the block's double_conv (tmp_utils.py:28-29), in place; MC-dropout inference only"""
+        if not dropout or blk not in DROP_BLOCKS:
+            return
+        keep = None
+        if dropout.get("tap") is not None:
+            keep = torch.empty(self.P[level] * cout, dtype=torch.uint8, device=self.dev)
+            dropout["tap"][blk] = (keep, level, cout)
+        H.call("nppc_dropout", self.prec, x, ldx, self.P[level], cout, float(dropout["p"]), int(dropout["seed"]),
+               int(dropout["pass_id"]) * len(DROP_BLOCKS) + DROP_BLOCKS.index(blk), keep, H.stream())
+
+    def forward(self, shape, maps, map_bstride, mask, out, out_pstride, xin=None, xin_bstride=0, train=False, dropout=None):
+        """dropout: None or dict(p, seed, pass_id[, tap]) -- MC-dropout passes (utils.py:334-338, 561-577).
+        maps: list of fp32 tensors holding [B][F*T] planes with batch stride `map_bstride` (the net's input
         channels); mask [B,T] fp32.  Writes out[(b*K+k)*out_pstride + f*T + t]:
           xin is None : U-Net(maps) * (1 - mask)                      (pc_wrapper.py:77-83)
           xin given   : xin * mask + U-Net(maps) * (1 - mask)         (RestorationWrapper, unet.py:299-312)"""
@@ -234,6 +247,7 @@ class UNetEngine:
                 x5 = self.buf("x5", 4, cout)
                 out_t, ldo = x5.t, cout
             self._double_conv(blk, path, cin, cout, level, x, ldx, out_t, ldo, train, saved)
+            self._dropout(blk, out_t, ldo, cout, level, dropout)
             x, ldx = out_t, ldo
         prev, prev_c, prev_level = x, 512, 4
         for blk, path, cin, cout, level in PLAN[5:]:
@@ -243,13 +257,14 @@ class UNetEngine:
             H.call("nppc_upsample2", self.prec, prev, prev_c, cat[level].at(cskip), cat[level].ld, prev_c, B, hi, wi, ht, wt, s)
             u = self.buf(blk + ".out", level, cout)
             self._double_conv(blk, path, cin, cout, level, cat[level].t, cat[level].ld, u.t, cout, train, saved)
+            self._dropout(blk, u.t, cout, cout, level, dropout)
             prev, prev_c, prev_level = u.t, cout, level
         raw_o = self.buf("raw_o", 0, OUT_LD)
         self._conv("outc.conv", 64, self.out_ch, 1, prev, 64, raw_o.t, OUT_LD, 0, False)
         H.call("nppc_unet_out", self.prec, raw_o.t, OUT_LD, mask, xin, xin_bstride, out, out_pstride, self.out_ch, B, F, T,
                0 if xin is None else 1, s)
         if train:
-            self.saved = dict(blocks=saved, pools=pools, u4=prev, mask=mask)
+            self.saved = None if dropout else dict(blocks=saved, pools=pools, u4=prev, mask=mask)
 
     def _pool_idx(self, level, n):
         key = ("pool_idx", level)

@@ -191,6 +191,28 @@ int nppc_time_to_spec_mask(const float* mask_time, float* mask_frames, int B, in
 int nppc_stft_pair(const float* wave, const float* mask_frames /*nullable*/, float* spec, float* masked_spec /*nullable*/,
                    int B, int L, int nfft, int hop, void* stream);
 
+/* ---- MC-dropout + PCA baseline (utils.py:334-648) -----------------------------------------------
+ * nn.Dropout(p) (tmp_utils.py:28-29) in place on channels [0, C) of a haloed NHWC activation X [rows][ld]:
+ * keep bit = Philox4x32-10(seed; row, channel / 4, stream_id) >= p * 2^32, kept values scaled by 1 / (1 - p);
+ * keep_out (nullable) [rows][C] u8 receives the bits. */
+int nppc_dropout(int prec, void* X, long ld, long rows, int C, float p, long seed, int stream_id,
+                 unsigned char* keep_out /*nullable*/, void* stream);
+/* compute_pca_sklearn_batch (utils.py:393-496) for all items at once: X [K][B][D] fp32 (K <= 60 samples per item) ->
+ * mean [B][D], comps [B][n][D] (unit, largest-magnitude entry positive), scaled = comps * singular value,
+ * svals [B][n], weights = svals / sum(svals) [B][n]; work = *elems of nppc_pca_work_elems doubles. */
+int nppc_pca_work_elems(int K, int B, int n, long* elems);
+int nppc_pca_batch(const float* X, int K, int B, int D, int n, float* mean, float* comps, float* scaled, float* svals,
+                   float* weights, double* work, void* stream);
+
+/* base_step2's projection loss (inpainting/trainer/nppc_trainer.py:285-323): rows w, m [B*K][N] (NPPC directions, scaled MC
+ * components), sv [B][K] -> proj, w_norms (= |w| + eps) [B][K], reconst, second [B]; sums [B*K*3] / coef [B*K*3] doubles are
+ * workspace kept for nppc_pair_loss_bwd: dw = d(sum_b grec[b] * reconst_b + g_rec_all * sum_b reconst_b
+ * + g_sm_all * sum_b second_b) / dw. */
+int nppc_pair_loss(const float* w, const float* m, const float* sv, double* sums, float* proj, float* w_norms, float* reconst,
+                   float* second, double* coef, int B, int K, long N, double eps, void* stream);
+int nppc_pair_loss_bwd(const float* w, const float* m, const double* coef, const float* grec /*nullable*/, float g_rec_all,
+                       float g_sm_all, float* dw, int B, int K, long N, void* stream);
+
 /* clip_grad_norm_(max_norm) + Adam without a host round trip (inpainting/trainer/nppc_trainer.py:149-154):
  * nppc_sumsq accumulates sum(g^2) into a zeroed device double, nppc_adam_step_clip reads it. */
 int nppc_sumsq(const float* g, long n, double* out, void* stream);

@@ -52,19 +52,23 @@ def _bn(x, P, pre, train, new_stats):
     return xh * P[pre + "weight"][None, :, None, None] + P[pre + "bias"][None, :, None, None]
 
 
-def double_conv(x, P, pre, train, new_stats, taps=None):
+def double_conv(x, P, pre, train, new_stats, taps=None, keep=None, p_drop=0.0):
     """tmp_utils.double_conv (tmp_utils.py:8-37): (conv3x3 pad 1 -> BatchNorm -> LeakyReLU(0.2)) x 2.
-    Dropout (down3/down4/up1/up2 of the restorer) is the identity: the restorer runs in eval mode
-    (nppc_model.py:95,113) and the direction U-Net is configured with dropout 0 (config_nppc.yaml:33-36)."""
+    Dropout (down3/down4/up1/up2 of the restorer) is the identity on the train path: the restorer runs in eval mode
+    (nppc_model.py:95,113) and the direction U-Net is configured with dropout 0 (config_nppc.yaml:33-36).
+    MC-dropout (utils.enable_dropout, utils.py:334-338): `keep` is the 0/1 keep mask of nn.Dropout(p_drop)
+    (tmp_utils.py:28-29), applied as x * keep / (1 - p)."""
     for ci, bi in ((0, 1), (3, 4)):
         x = F.conv2d(x, P[f"{pre}{ci}.weight"], P[f"{pre}{ci}.bias"], padding=1)
         if taps is not None:
             taps[f"{pre}{ci}.raw"] = x
         x = F.leaky_relu(_bn(x, P, f"{pre}{bi}.", train, new_stats), LEAK)
+    if keep is not None:
+        x = x * keep.to(x.dtype) / (1.0 - p_drop)
     return x
 
 
-def unet_forward(x, P, pre="", train=False, new_stats=None, taps=None):
+def unet_forward(x, P, pre="", train=False, new_stats=None, taps=None, keep=None, p_drop=0.0):
     """UNet.forward (inpainting/networks/unet.py:277-290) with down = MaxPool2d(2) + double_conv
     (tmp_utils.py:50-60) and up = bilinear x2 (align_corners=True) + pad-to-skip + cat([skip, up]) +
     double_conv (tmp_utils.py:63-91), outc = 1x1 conv (tmp_utils.py:94-99)."""
@@ -73,7 +77,7 @@ def unet_forward(x, P, pre="", train=False, new_stats=None, taps=None):
     for blk, path, _, _ in UNET_PLAN[:5]:
         if blk != "inc":
             h = F.max_pool2d(h, 2)
-        h = double_conv(h, P, f"{pre}{blk}.{path}.", train, new_stats, taps)
+        h = double_conv(h, P, f"{pre}{blk}.{path}.", train, new_stats, taps, None if keep is None else keep.get(blk), p_drop)
         feats.append(h)
         if taps is not None:
             taps[f"{pre}{blk}.out"] = h
@@ -82,7 +86,8 @@ def unet_forward(x, P, pre="", train=False, new_stats=None, taps=None):
         h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
         dy, dx = skip.shape[2] - h.shape[2], skip.shape[3] - h.shape[3]
         h = F.pad(h, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
-        h = double_conv(torch.cat([skip, h], dim=1), P, f"{pre}{blk}.{path}.", train, new_stats, taps)
+        h = double_conv(torch.cat([skip, h], dim=1), P, f"{pre}{blk}.{path}.", train, new_stats, taps,
+                        None if keep is None else keep.get(blk), p_drop)
         if taps is not None:
             taps[f"{pre}{blk}.out"] = h
     return F.conv2d(h, P[pre + "outc.conv.weight"], P[pre + "outc.conv.bias"])
@@ -222,3 +227,59 @@ def inpaint_sample(clean, start, end, nfft=255, hop=128, win=255):
     spec = stft_pair(clean, nfft, hop, win)
     mf = time_to_spec_mask(mask, spec.shape[3], L, win, hop).to(clean.dtype)
     return (spec * mf[None, None, None, :])[0], mf, spec[0], clean * mask
+
+
+# ---- MC-dropout + PCA baseline ---------------------------------------------------------
+def pca_batch(outputs, n_components=5):
+    """compute_pca_sklearn_batch (utils.py:393-496) restated with an exact SVD: outputs [K,B,D] ->
+    (components [B,n,D], components * singular value, singular / sum(kept singular) [B,n], mean [B,D], singular [B,n]).
+    Sign: sklearn.utils.extmath.svd_flip(u_based_decision=False) -- the largest-magnitude entry of each component is
+    positive.  (scikit-learn picks its RANDOMIZED solver for 50 x ~1800 inputs, so the reference's own numbers are an
+    approximation of these; compute_pca_and_importance_weights, utils.py:498-545, is the exact torch.linalg.svd variant
+    without the sign rule.)"""
+    K, B, D = outputs.shape
+    n = min(n_components, K)
+    pcs, scaled, wts, means, svs = [], [], [], [], []
+    for b in range(B):
+        x = outputs[:, b, :]
+        mean = x.mean(dim=0)
+        U, S, Vh = torch.linalg.svd((x - mean).double(), full_matrices=False)
+        V, S = Vh[:n], S[:n]
+        idx = V.abs().argmax(dim=1)
+        V = V * torch.sign(V[torch.arange(n), idx])[:, None]
+        pcs.append(V)
+        scaled.append(V * S[:, None])
+        wts.append(S / S.sum())
+        means.append(mean)
+        svs.append(S)
+    return torch.stack(pcs), torch.stack(scaled), torch.stack(wts), torch.stack(means), torch.stack(svs)
+
+
+def scatter_gap(values, mask4):
+    """reconstruct_full_spec_batch (utils.py:600-625): values [B,N] or [B,n,N] -> zeros with the gap (mask == 0) filled"""
+    B, _, Fq, T = mask4.shape
+    hole = (mask4.reshape(B, Fq * T) == 0)
+    if values.dim() == 3:
+        out = torch.zeros(B, values.shape[1], Fq * T, dtype=values.dtype)
+        for b in range(B):
+            out[b][:, hole[b]] = values[b]
+        return out.reshape(B, values.shape[1], Fq, T)
+    out = torch.zeros(B, Fq * T, dtype=values.dtype)
+    for b in range(B):
+        out[b][hole[b]] = values[b]
+    return out.reshape(B, Fq, T)
+
+
+def base_step2_loss(w_mat, w_mc, singular_values, lam):
+    """base_step2's loss terms (inpainting/trainer/nppc_trainer.py:255-323): row-normalised (norm + 1e-6) NPPC
+    directions against row-normalised scaled MC components -> (reconst_err [B], second_moment_mse [B], objective,
+    proj [B,K], w_norms [B,K])."""
+    w_ = w_mat.flatten(2)
+    w_norms = w_.norm(dim=2) + 1e-6
+    w_hat = w_ / w_norms[:, :, None]
+    m_ = w_mc.flatten(2)
+    m_hat = m_ / (m_.norm(dim=2) + 1e-6)[:, :, None]
+    proj = (w_hat * m_hat).sum(dim=2)
+    reconst_err = (1 - proj.pow(2)).mean(dim=1)
+    second = (w_norms.pow(2) - singular_values.pow(2)).pow(2).mean(dim=1)
+    return reconst_err, second, reconst_err.mean() + lam * second.mean(), proj, w_norms

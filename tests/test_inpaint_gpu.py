@@ -403,3 +403,183 @@ def test_synthesised_batch_feeds_the_train_step():
     assert torch.isfinite(obj) and float(rec.min()) > -1e-4 and float(rec.max()) < 1 + 1e-4
     w = log["w_mat"]
     assert float(w[mf.bool()[:, None, None, :].expand_as(w)].abs().max()) == 0.0
+
+
+# ---- row f4: MC-dropout + PCA baseline ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mc50", "small", "odd"])
+def test_pca_batch_against_reference_pca_goldens(name):
+    """batched Gram + Jacobi + components (csrc/mc_pca.hip) against the outputs of the reference's
+    compute_pca_sklearn_batch (tests/golden/pca.npz) and the fp64 oracle"""
+    from nppc_audio.inpainting.mc_baseline import compute_pca_batch
+    z = np.load(os.path.join(GOLD, "pca.npz"))
+    x = torch.from_numpy(z[f"{name}_x"])
+    pcs, scaled, w, mean, sv = (t.cpu().numpy() for t in compute_pca_batch(x.cuda(), 5))
+    assert np.abs(pcs - z[f"{name}_pcs"]).max() < 2e-5
+    assert np.abs(sv - z[f"{name}_svals"]).max() < 2e-6 * z[f"{name}_svals"].max()
+    assert np.abs(scaled - z[f"{name}_scaled"]).max() < 2e-5 * np.abs(z[f"{name}_scaled"]).max()
+    assert np.abs(w - z[f"{name}_weights"]).max() < 1e-6 and np.abs(mean - z[f"{name}_mean"]).max() < 5e-6
+    o = [t.numpy() for t in R.pca_batch(x, 5)]
+    assert np.abs(pcs - o[0]).max() < 5e-6 and np.abs(sv - o[4]).max() < 1e-6 * o[4].max()
+    # properties: orthonormal components, scaled = component * singular value
+    g = np.einsum("bid,bjd->bij", pcs.astype(np.float64), pcs.astype(np.float64))
+    assert np.abs(g - np.eye(g.shape[1])).max() < 1e-5
+    assert np.abs(scaled - pcs * sv[:, :, None]).max() < 1e-6 * sv.max()
+
+
+def test_pca_batch_edge_cases():
+    from nppc_audio.inpainting.mc_baseline import compute_pca_batch
+    g = torch.Generator().manual_seed(3)
+    # more components than samples -> min(n, K); K = 2; a constant stack (all singular values 0) stays finite
+    x = torch.randn(2, 3, 40, generator=g)
+    pcs, scaled, w, mean, sv = compute_pca_batch(x.cuda(), 5)
+    assert pcs.shape == (3, 2, 40) and sv.shape == (3, 2)
+    o = R.pca_batch(x, 5)
+    assert float((pcs[:, 0].cpu() - o[0][:, 0]).abs().max()) < 1e-5 and float((sv.cpu() - o[4]).abs().max()) < 1e-5
+    c = torch.ones(6, 1, 33)
+    pcs, scaled, w, mean, sv = compute_pca_batch(c.cuda(), 3)
+    assert float(sv.abs().max()) == 0.0 and bool(torch.isfinite(pcs).all()) and float(mean.min()) == 1.0
+    with pytest.raises(RuntimeError, match="unsupported"):
+        compute_pca_batch(torch.zeros(61, 1, 8).cuda(), 3)
+
+
+def _dropout_unet(precision, seed=0):
+    from nppc_audio.inpainting.networks.unet import RestorationWrapper, UNet, UNetConfig
+    spec = W.unet_spec(1, 1)
+    wts = {k: torch.from_numpy(v) for k, v in W.make_weights(spec, 21).items()}
+    net = UNet(UNetConfig(in_channels=1, out_channels=1, dropout=0.2, precision=precision))
+    net.load_state_dict(wts, strict=True)
+    net.dropout_seed = 1234 + seed
+    return RestorationWrapper(net).cuda().eval(), wts
+
+
+def _tap_to_nchw(tap, B, H, Wd):
+    keep, level, C = tap
+    return keep.reshape(B, H + 2, Wd + 2, C)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu()
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_mc_dropout_pass_against_oracle_with_the_same_keep_masks(precision, tol):
+    """one stochastic pass: the keep bits the kernel drew (tapped) fed to the oracle's U-Net -> same output; the bits
+    are Bernoulli(0.8), differ between passes, repeat for the same (seed, pass)"""
+    from nppc_audio.inpainting.mc_baseline import enable_dropout
+    B, Fq, T = 2, 32, 37
+    model, wts = _dropout_unet(precision)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 1, Fq, T, generator=g)
+    mask = torch.ones(B, 1, Fq, T)
+    mask[:, :, :, 10:17] = 0
+    enable_dropout(model)
+    assert not model.net.training and all(m.training for m in model.net.modules() if isinstance(m, torch.nn.Dropout))
+    model.net.dropout_tap = {}
+    with torch.no_grad():
+        y0 = model(x.cuda(), mask.cuda()).cpu()
+    taps0 = dict(model.net.dropout_tap)
+    dims = {"down3": (Fq // 8, T // 8), "down4": (Fq // 16, T // 16), "up1": (Fq // 8, T // 8), "up2": (Fq // 4, T // 4)}
+    keep = {blk: _tap_to_nchw(taps0[blk], B, *dims[blk]) for blk in dims}
+    frac = np.mean([float(k.mean()) for k in keep.values()])
+    assert 0.77 < frac < 0.83, frac
+    P = {k: v.double() for k, v in wts.items()}
+    want = R.unet_forward(x.double(), P, "", train=False, keep={k: v.double() for k, v in keep.items()}, p_drop=0.2)
+    want = x.double() * mask + want * (1 - mask)
+    assert rel(y0.numpy(), want.numpy()) < tol
+    # second pass: new bits, different output in the gap, identical known frames
+    model.net.dropout_tap = {}
+    with torch.no_grad():
+        y1 = model(x.cuda(), mask.cuda()).cpu()
+    assert not torch.equal(model.net.dropout_tap["down4"][0], taps0["down4"][0])
+    assert float((y1 - y0).abs().max()) > 1e-3 and torch.equal((y1 * mask), (y0 * mask))
+    # replaying pass 0 reproduces it bit for bit
+    model.net.dropout_pass = 0
+    model.net.dropout_tap = {}
+    with torch.no_grad():
+        y2 = model(x.cuda(), mask.cuda()).cpu()
+    assert torch.equal(y2, y0) and torch.equal(model.net.dropout_tap["up2"][0], taps0["up2"][0])
+    # eval mode again (dropout modules back to eval): deterministic identity dropout == the plain restorer
+    model.eval()
+    with torch.no_grad():
+        y3 = model(x.cuda(), mask.cuda()).cpu()
+    plain = R.restorer_forward(x.double(), mask.double(), {"n." + k: v for k, v in P.items()}, pre="n.")
+    assert rel(y3.numpy(), plain.numpy()) < tol
+
+
+def test_calculate_unet_baseline_end_to_end():
+    """calculate_unet_baseline's dict: shapes, support on the gap only, PCA of the very samples the passes produced
+    (oracle PCA on the sampled stack), importance weights sum to 1"""
+    from nppc_audio.inpainting import mc_baseline as MB
+    B, Fq, T, K = 3, 32, 40, 12
+    model, _ = _dropout_unet("fp32", seed=5)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 1, Fq, T, generator=g).cuda()
+    mask = torch.ones(B, 1, Fq, T)
+    for b, s in enumerate((5, 17, 30)):
+        mask[b, :, :, s:s + 6] = 0
+    mask = mask.cuda()
+    out = MB.calculate_unet_baseline(model, x, mask, n_mc_samples=K, n_components=5)
+    assert out["mean_prediction"].shape == (B, 1, Fq, T) and out["principal_components"].shape == (B, 5, Fq, T)
+    assert out["scaled_principal_components"].shape == (B, 5, Fq, T) and out["singular_vals"].shape == (B, 5)
+    known = mask.bool().expand(-1, 5, -1, -1)
+    assert float(out["principal_components"][known].abs().max()) == 0.0
+    assert float(out["mean_prediction"][mask.bool()].abs().max()) == 0.0
+    assert torch.allclose(out["importance_weights"].sum(1), torch.ones(B, device="cuda"), atol=1e-5)
+    # replay the same K passes and run the oracle PCA on that stack
+    model.net.dropout_pass = 0
+    preds, hole = MB.mc_dropout_samples(model, x, mask, K)
+    o = R.pca_batch(preds.cpu(), 5)
+    full = R.scatter_gap(o[0].float(), mask.cpu())
+    assert float((out["principal_components"].cpu() - full).abs().max()) < 2e-4
+    assert float((out["singular_vals"].cpu() - o[4].float()).abs().max()) < 1e-4 * float(o[4].max())
+    assert float((out["mean_prediction"][:, 0].cpu() - R.scatter_gap(o[3].float(), mask.cpu())).abs().max()) < 1e-5
+    with pytest.raises(ValueError, match="same number of masked"):
+        bad = mask.clone()
+        bad[0, :, :, 0] = 0
+        MB.mc_dropout_samples(model, x, bad, 2)
+
+
+def test_base_step2_loss_and_gradient_against_oracle():
+    """PairProjectionLoss (nppc_pair_loss / _bwd) against the fp64 torch restatement of nppc_trainer.py:285-323"""
+    from nppc_audio.inpainting.mc_baseline import PairProjectionLoss
+    g = torch.Generator().manual_seed(8)
+    B, K, Fq, T = 3, 5, 16, 23
+    w = torch.randn(B, K, Fq, T, generator=g) * torch.rand(B, K, 1, 1, generator=g) * 3
+    m = torch.randn(B, K, Fq, T, generator=g) + 0.5 * w
+    sv = torch.rand(B, K, generator=g) * 20
+    gr = torch.randn(B, generator=g)
+    for lam in (1e-6, 0.7):
+        wd = w.double().requires_grad_(True)
+        rec_o, sm_o, obj_o, proj_o, wn_o = R.base_step2_loss(wd, m.double(), sv.double(), lam)
+        (obj_o * 1.3 + (rec_o * gr.double()).sum()).backward()
+        wg = w.cuda().requires_grad_(True)
+        rec, obj, proj, wn, sm = PairProjectionLoss.apply(wg, m.cuda(), sv.cuda(), lam)
+        (obj * 1.3 + (rec * gr.cuda()).sum()).backward()
+        assert rel(rec.detach().cpu(), rec_o.detach()) < 1e-5 and rel(sm.cpu(), sm_o.detach()) < 1e-5
+        assert abs(float(obj) - float(obj_o)) < 1e-5 * abs(float(obj_o))
+        assert rel(proj.cpu(), proj_o.detach()) < 1e-5 and rel(wn.cpu(), wn_o.detach()) < 1e-6
+        assert rel(wg.grad.cpu(), wd.grad) < 1e-5
+
+
+def test_base_step2_runs_on_the_trainer():
+    """the alternative-target step end to end: MC passes with the restorer in train mode, PCA, projection loss, backward"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import bench_inpainting as bi
+    B, Fq, T = 4, 128, 80
+    tr = bi.build("fp32", B, Fq, T)
+    masked, mask, clean = bi.synth(B, Fq, T, "cuda")
+    tr.step = 500
+    before = tr.nppc_model.pretrained_restoration_model.net.state_dict()["down3.mpconv.1.conv.1.running_mean"].clone()
+    rec, obj, log = tr.base_step2((masked, mask, clean), n_mc_samples=8)
+    tr.nppc_model.zero_grad()
+    obj.backward()
+    torch.cuda.synchronize()
+    assert set(log) == {"w_mat", "w_mc", "proj_W_mc_on_W_nppc", "w_norms", "reconst_err", "second_moment_mse", "objective"}
+    assert log["w_mc"].shape == log["w_mat"].shape and log["proj_W_mc_on_W_nppc"].shape == (B, bi.K_DIRS)
+    assert torch.isfinite(obj) and float(rec.min()) > -1e-5 and float(rec.max()) < 1 + 1e-5
+    grad = tr.nppc_model.pc_wrapper.net.engine().fp.grad
+    assert bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0
+    net = tr.nppc_model.pretrained_restoration_model.net
+    assert not net.training and not any(m.training for m in net.modules())
+    after = net.state_dict()["down3.mpconv.1.conv.1.running_mean"]
+    assert not torch.equal(before, after)           # restoration_model.train(): the reference moves these buffers too
+    # the w_mc rows are the scaled components: their norms are the singular values
+    n = log["w_mc"].flatten(2).norm(dim=2)
+    assert float(n.min()) > 0

@@ -167,3 +167,22 @@ def test_batch_synthesis_oracle_matches_reference_dataset(name):
         assert np.array_equal(sm.numpy(), z[f"{name}_stft_masked"][i])
         assert np.array_equal(ma[0].numpy(), z[f"{name}_masked_audio"][i])
         assert 0 < int((mf == 0).sum()) < mf.numel()
+
+
+@pytest.mark.parametrize("name", ["mc50", "small", "odd"])
+def test_pca_oracle_matches_reference_pca(name):
+    """row f4: the oracle's exact-SVD restatement against the reference's compute_pca_sklearn_batch (scikit-learn,
+    randomized solver, seeded) and compute_pca_and_importance_weights (torch.linalg.svd; sign free) outputs."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import inpaint_ref as IR
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pca.npz"))
+    pcs, scaled, w, mean, sv = (t.numpy() for t in IR.pca_batch(torch.from_numpy(z[f"{name}_x"]), 5))
+    assert np.abs(pcs - z[f"{name}_pcs"]).max() < 2e-5                       # unit vectors, sign rule included
+    assert np.abs(sv - z[f"{name}_svals"]).max() < 2e-6 * z[f"{name}_svals"].max()
+    assert np.abs(scaled - z[f"{name}_scaled"]).max() < 2e-5 * np.abs(z[f"{name}_scaled"]).max()
+    assert np.abs(w - z[f"{name}_weights"]).max() < 1e-6 and np.abs(mean - z[f"{name}_mean"]).max() < 5e-6
+    p2 = z[f"{name}_svd_pcs"]
+    sgn = np.sign((pcs * p2).sum(-1, keepdims=True))
+    assert np.abs(pcs - sgn * p2).max() < 2e-5 and np.abs(w - z[f"{name}_svd_weights"]).max() < 1e-6
