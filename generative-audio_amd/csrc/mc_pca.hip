@@ -291,6 +291,36 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) dr[i] = alpha * mr[i] + beta * wr[i];
 }
 
+// ------------------------------------------------------------------------------------------------ compute_metrics
+// validator_nppc_model.py:742-828: every number it reports is a function of inner products between the direction rows
+// and three error rows.  metric_rows builds the error rows, rows_gram the inner products (fp64); the 5 x 5 algebra
+// (norms, residual, principal angles) is host-side.
+__global__ __launch_bounds__(256) void metric_rows_kernel(const float* __restrict__ pred, const float* __restrict__ clean,
+                                                          const float* __restrict__ mean, const float* __restrict__ mask,
+                                                          float* __restrict__ out, long N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float hole = mask[i] == 0.f ? 1.f : 0.f;
+  const float e = pred[i] - clean[i];
+  out[i] = e;                                   // error (:807), used unmasked by compute_residual_error_magnitude
+  out[N + i] = e * hole;                        // compute_rmse(pred, clean, mask)  (:758-762)
+  out[2 * N + i] = (mean[i] - clean[i]) * hole; // compute_rmse(mean_prediction, clean, mask)
+}
+
+__global__ __launch_bounds__(256) void rows_gram_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int Rb,
+                                                        long N, double* __restrict__ G) {
+  __shared__ double red[4];
+  const int pair = blockIdx.y, i = pair / Rb, j = pair % Rb, tid = threadIdx.x;
+  const float* a = A + (size_t)i * N;
+  const float* b = Bm + (size_t)j * N;
+  double s = 0.0;
+  for (long k = (long)blockIdx.x * 256 + tid; k < N; k += (long)gridDim.x * 256) s += (double)a[k] * (double)b[k];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&G[pair], red[0] + red[1] + red[2] + red[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -361,6 +391,25 @@ int nppc_pair_loss_bwd(const float* w, const float* m, const double* coef, const
   const int chunks = (int)(N / 2048 + 1 > 64 ? 64 : N / 2048 + 1);
   hipLaunchKernelGGL(pair_bwd_kernel, dim3(chunks, B * K), dim3(256), 0, (hipStream_t)stream, w, m, coef, grec, g_rec_all,
                      g_sm_all, dw, K, N);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_metric_rows(const float* pred, const float* clean, const float* mean, const float* mask, float* out, long N,
+                     void* stream) {
+  if (!pred || !clean || !mean || !mask || !out || N <= 0) return NPPC_EBADARG;
+  hipLaunchKernelGGL(metric_rows_kernel, dim3(ceil_div(N, 256L)), dim3(256), 0, (hipStream_t)stream, pred, clean, mean, mask, out,
+                     N);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_rows_gram(const float* A, int Ra, const float* Bm, int Rb, long N, double* G, void* stream) {
+  if (!A || !Bm || !G || Ra <= 0 || Rb <= 0 || N <= 0 || (long)Ra * Rb > 65535) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(G, 0, sizeof(double) * (size_t)Ra * Rb, s) != hipSuccess) return NPPC_ELAUNCH;
+  const int chunks = (int)(N / 8192 + 1 > 32 ? 32 : N / 8192 + 1);
+  hipLaunchKernelGGL(rows_gram_kernel, dim3(chunks, Ra * Rb), dim3(256), 0, s, A, Bm, Rb, N, G);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -123,6 +123,8 @@ SIGS = {
     "nppc_pca_batch": [P, I, I, I, I, P, P, P, P, P, P, P],
     "nppc_pair_loss": [P, P, P, P, P, P, P, P, P, I, I, L, D, P],
     "nppc_pair_loss_bwd": [P, P, P, P, F, F, P, I, I, L, P],
+    "nppc_metric_rows": [P, P, P, P, P, L, P],
+    "nppc_rows_gram": [P, I, P, I, L, P, P],
     "nppc_sumsq": [P, L, P, P],
     "nppc_adam_step_clip": [P, P, P, P, L, D, D, D, D, D, I, D, P, D, P],
     "nppc_logmag": [P, P, L, I, L, P, P],

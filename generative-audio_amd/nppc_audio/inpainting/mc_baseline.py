@@ -128,3 +128,45 @@ class PairProjectionLoss(torch.autograd.Function):
         dw = torch.empty_like(w)
         H.call("nppc_pair_loss_bwd", w, m, coef, grec, go / B, go * ctx.lam / B, dw, B, K, N, H.stream())
         return dw, None, None, None
+
+
+def compute_metrics(nppc_directions, mc_dropout_directions, pred_spec_mag, mean_prediction, clean_spec_mag, mask):
+    """validator_nppc_model.compute_metrics (inpainting/validator/validator_nppc_model.py:742-828) for one item:
+    directions [1,n,F,T] x2, pred / mean / clean / mask [1,1,F,T] -> {'nppc': {rmse, residual_error},
+    'mc_dropout': {rmse, residual_error}, 'principal_angles': [degrees]}.  All inner products come from ONE device
+    Gram of the 2n + 3 rows; the n x n algebra (whitening instead of QR: same singular values) is host numpy fp64."""
+    import numpy as np
+    H.require_gpu()
+    n = nppc_directions.shape[1]
+    N = nppc_directions[0, 0].numel()
+    assert nppc_directions.shape[0] == 1 and mc_dropout_directions.shape == nppc_directions.shape
+    dev = nppc_directions.device
+    rows = torch.empty(2 * n + 3, N, dtype=torch.float32, device=dev)
+    rows[:n].copy_(nppc_directions.reshape(n, N))
+    rows[n:2 * n].copy_(mc_dropout_directions.reshape(n, N))
+    s = H.stream()
+    f32 = lambda t: t.contiguous().float()
+    H.call("nppc_metric_rows", f32(pred_spec_mag), f32(clean_spec_mag), f32(mean_prediction), f32(mask), rows[2 * n:], N, s)
+    G = torch.empty(2 * n + 3, 2 * n + 3, dtype=torch.float64, device=dev)
+    H.call("nppc_rows_gram", rows, 2 * n + 3, rows, 2 * n + 3, N, G, s)
+    G = G.cpu().numpy()
+    e, e_np, e_mc = 2 * n, 2 * n + 1, 2 * n + 2
+
+    def residual(idx):
+        norms = np.sqrt(np.diag(G)[idx]) + 1e-6
+        c = G[idx, e] / norms                                     # W^T e
+        gh = G[np.ix_(idx, idx)] / np.outer(norms, norms)
+        return float(np.sqrt(max(G[e, e] - 2.0 * (c * c).sum() + c @ gh @ c, 0.0)))
+
+    def whiten(idx):
+        lam, U = np.linalg.eigh(G[np.ix_(idx, idx)])
+        keep = lam > 1e-12 * lam.max()
+        return U[:, keep] / np.sqrt(lam[keep])                    # columns w: (w^T A) rows are orthonormal
+
+    a, b = np.arange(n), np.arange(n, 2 * n)
+    sv = np.linalg.svd(whiten(a).T @ G[np.ix_(a, b)] @ whiten(b), compute_uv=False)
+    return {
+        'nppc': {'rmse': float(np.sqrt(G[e_np, e_np])), 'residual_error': residual(a)},
+        'mc_dropout': {'rmse': float(np.sqrt(G[e_mc, e_mc])), 'residual_error': residual(b)},
+        'principal_angles': (np.arccos(np.clip(sv, -1, 1)) * 180 / np.pi).tolist(),
+    }

@@ -213,6 +213,12 @@ int nppc_pair_loss(const float* w, const float* m, const float* sv, double* sums
 int nppc_pair_loss_bwd(const float* w, const float* m, const double* coef, const float* grec /*nullable*/, float g_rec_all,
                        float g_sm_all, float* dw, int B, int K, long N, void* stream);
 
+/* compute_metrics (inpainting/validator/validator_nppc_model.py:742-828): out [3][N] = {pred - clean, the same on the gap
+ * only (mask == 0), (mean - clean) on the gap only}; nppc_rows_gram: G [Ra][Rb] (fp64) = A [Ra][N] . Bm [Rb][N]^T */
+int nppc_metric_rows(const float* pred, const float* clean, const float* mean, const float* mask, float* out, long N,
+                     void* stream);
+int nppc_rows_gram(const float* A, int Ra, const float* Bm, int Rb, long N, double* G, void* stream);
+
 /* clip_grad_norm_(max_norm) + Adam without a host round trip (inpainting/trainer/nppc_trainer.py:149-154):
  * nppc_sumsq accumulates sum(g^2) into a zeroed device double, nppc_adam_step_clip reads it. */
 int nppc_sumsq(const float* g, long n, double* out, void* stream);

@@ -283,3 +283,30 @@ def base_step2_loss(w_mat, w_mc, singular_values, lam):
     reconst_err = (1 - proj.pow(2)).mean(dim=1)
     second = (w_norms.pow(2) - singular_values.pow(2)).pow(2).mean(dim=1)
     return reconst_err, second, reconst_err.mean() + lam * second.mean(), proj, w_norms
+
+
+def compute_metrics(nppc_directions, mc_dropout_directions, pred_spec_mag, mean_prediction, clean_spec_mag, mask):
+    """validator_nppc_model.compute_metrics (validator_nppc_model.py:742-828), one item: gap-only RMSE of the two
+    predictions, ||e - W W^T e|| with row-normalised (norm + 1e-6) directions and the UNMASKED error, principal angles
+    (QR bases, svdvals, degrees)."""
+    import numpy as np
+
+    def rmse(p):
+        return torch.norm((p - clean_spec_mag)[mask == 0]).item()
+
+    def residual(err, dirs):
+        ef = err.reshape(err.shape[1], -1)
+        d = dirs.reshape(dirs.shape[1], -1)
+        d = d / (d.norm(dim=1) + 1e-6)[:, None]
+        return torch.norm(ef.T - d.T @ (d @ ef.T)).item()
+
+    def angles(a, b):
+        qa, _ = torch.linalg.qr(a.reshape(a.shape[1], -1).T)
+        qb, _ = torch.linalg.qr(b.reshape(b.shape[1], -1).T)
+        s = torch.linalg.svdvals(qa.T @ qb)
+        return (torch.arccos(torch.clamp(s, -1, 1)) * 180 / np.pi).tolist()
+
+    err = pred_spec_mag - clean_spec_mag
+    return {"nppc": {"rmse": rmse(pred_spec_mag), "residual_error": residual(err, nppc_directions)},
+            "mc_dropout": {"rmse": rmse(mean_prediction), "residual_error": residual(err, mc_dropout_directions)},
+            "principal_angles": angles(nppc_directions, mc_dropout_directions)}

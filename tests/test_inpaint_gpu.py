@@ -583,3 +583,15 @@ def test_base_step2_runs_on_the_trainer():
     # the w_mc rows are the scaled components: their norms are the singular values
     n = log["w_mc"].flatten(2).norm(dim=2)
     assert float(n.min()) > 0
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_compute_metrics_against_reference_goldens(case):
+    """device Gram + host 5 x 5 algebra against the reference's own compute_metrics output (tests/golden/metrics.npz)"""
+    from nppc_audio.inpainting.mc_baseline import compute_metrics
+    z = np.load(os.path.join(GOLD, "metrics.npz"))
+    t = {k: torch.from_numpy(z[f"{case}_{k}"]).cuda() for k in ("nppc", "mc", "pred", "mean", "clean", "mask")}
+    m = compute_metrics(t["nppc"], t["mc"], t["pred"], t["mean"], t["clean"], t["mask"])
+    got = np.array([m["nppc"]["rmse"], m["nppc"]["residual_error"], m["mc_dropout"]["rmse"], m["mc_dropout"]["residual_error"]])
+    assert np.abs(got - z[f"{case}_scalars"]).max() < 2e-6 * z[f"{case}_scalars"].max()
+    assert np.abs(np.array(m["principal_angles"]) - z[f"{case}_angles"]).max() < 1e-3      # degrees; reference is fp32

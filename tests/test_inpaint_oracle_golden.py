@@ -186,3 +186,17 @@ def test_pca_oracle_matches_reference_pca(name):
     p2 = z[f"{name}_svd_pcs"]
     sgn = np.sign((pcs * p2).sum(-1, keepdims=True))
     assert np.abs(pcs - sgn * p2).max() < 2e-5 and np.abs(w - z[f"{name}_svd_weights"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_metrics_oracle_matches_reference_compute_metrics(case):
+    import os
+    import numpy as np
+    import torch
+    from oracle import inpaint_ref as IR
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics.npz"))
+    t = {k: torch.from_numpy(z[f"{case}_{k}"]) for k in ("nppc", "mc", "pred", "mean", "clean", "mask")}
+    m = IR.compute_metrics(t["nppc"], t["mc"], t["pred"], t["mean"], t["clean"], t["mask"])
+    got = np.array([m["nppc"]["rmse"], m["nppc"]["residual_error"], m["mc_dropout"]["rmse"], m["mc_dropout"]["residual_error"]])
+    assert np.abs(got - z[f"{case}_scalars"]).max() < 1e-6 * z[f"{case}_scalars"].max()
+    assert np.abs(np.array(m["principal_angles"]) - z[f"{case}_angles"]).max() < 1e-3
