@@ -263,9 +263,13 @@ __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __rest
 // M1[b][i][i] = -gr_b * A0 + gs * A1 ; M1[b][i][K] = -gr_b * E   (gr_b = dL/d reconst_b, gs = dL/d sm)
 __global__ void loss_bwd_coef_kernel(const double* __restrict__ coefA, const double* __restrict__ coefE,
                                      const float* __restrict__ grec, float gobj_over_B, float gsm, double* __restrict__ M1,
-                                     int B, int K) {
+                                     int B, int K, const float* __restrict__ gobj_dev) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (gobj_dev) {            // upstream d L / d objective stays on the device: no host read-back inside backward()
+    gobj_over_B *= *gobj_dev;
+    gsm *= *gobj_dev;
+  }
   const int KV = K + 1;
   double* M = M1 + (size_t)b * KV * KV * 2;
   for (int i = 0; i < KV * KV * 2; ++i) M[i] = 0.0;
@@ -376,7 +380,16 @@ int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* gr
                        int B, int K, void* stream) {
   if (!coefA || !coefE || !M1) return NPPC_EBADARG;
   hipLaunchKernelGGL(loss_bwd_coef_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, coefA, coefE, grec,
-                     gobj_over_B, gsm, M1, B, K);
+                     gobj_over_B, gsm, M1, B, K, (const float*)nullptr);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_loss_bwd_coef_dev(const double* coefA, const double* coefE, const float* grec, const float* gobj, float inv_B,
+                           float sm_weight, double* M1, int B, int K, void* stream) {
+  if (!coefA || !coefE || !M1 || !gobj) return NPPC_EBADARG;
+  hipLaunchKernelGGL(loss_bwd_coef_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, coefA, coefE, grec, inv_B,
+                     sm_weight, M1, B, K, gobj);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -407,9 +407,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ in,
 }
 
 // dst[n][k] (ld = ldd, zero padded) = src[n][k] * (colscale ? colscale[k] : 1), n < N, k < K;  T = bf16 / f32
+// blockIdx.y = matrix (a, b) of an n_a x n_b grid of equally shaped matrices with constant strides (TCN layers x branches)
 template <typename T>
 __global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int K, int Npad, int ldd,
-                                   int transpose) {
+                                   int transpose, int n_b, long ssa, long ssb, long dsa, long dsb) {
+  src += (size_t)(blockIdx.y / n_b) * ssa + (size_t)(blockIdx.y % n_b) * ssb;
+  dst += (size_t)(blockIdx.y / n_b) * dsa + (size_t)(blockIdx.y % n_b) * dsb;
   const long total = (long)Npad * ldd;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int nn = (int)(e / ldd), k = (int)(e % ldd);
@@ -514,9 +517,27 @@ int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Np
   const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16)
-    hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, N, K, Npad, ldd, transpose);
+    hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)dst, N, K, Npad, ldd, transpose, 1,
+                       0L, 0L, 0L, 0L);
   else
-    hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, N, K, Npad, ldd, transpose);
+    hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, N, K, Npad, ldd, transpose, 1, 0L,
+                       0L, 0L, 0L);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_pack_matrix_batched(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, int n_a,
+                             int n_b, long src_stride_a, long src_stride_b, long dst_stride_a, long dst_stride_b, void* stream) {
+  if (!src || !dst || N > Npad || K > ldd || n_a <= 0 || n_b <= 0 || (long)n_a * n_b > 65535) return NPPC_EBADARG;
+  const long total = (long)Npad * ldd;
+  const int gx = (int)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, dim3(gx, n_a * n_b), dim3(256), 0, s, src, (bf16_t*)dst, N, K, Npad, ldd,
+                       transpose, n_b, src_stride_a, src_stride_b, dst_stride_a, dst_stride_b);
+  else
+    hipLaunchKernelGGL(pack_matrix_kernel<float>, dim3(gx, n_a * n_b), dim3(256), 0, s, src, (float*)dst, N, K, Npad, ldd,
+                       transpose, n_b, src_stride_a, src_stride_b, dst_stride_a, dst_stride_b);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

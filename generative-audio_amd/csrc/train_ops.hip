@@ -44,6 +44,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ M, fl
   atomicAdd(out + c, s);
 }
 
+// the same for 16-byte aligned rows padded to a multiple of 8 columns (pad columns are read, never written): a workgroup covers 256 columns (32 lanes x 8 channels, one 16-byte
+// load per lane and row) x CS_ROWS rows (8 row lanes, CS_ROWS / 8 independent loads in flight per thread)
+constexpr int CS_ROWS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ M, float* __restrict__ out, int rows, int cols,
+                                                      long ld, long sM, long sOut) {
+  __shared__ float part[8][256 + 8];
+  M += (size_t)blockIdx.z * sM;
+  out += (size_t)blockIdx.z * sOut;
+  const int cl = (threadIdx.x & 31) * 8, c = blockIdx.x * 256 + cl, rl = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * CS_ROWS;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  if (c < cols) {
+#pragma unroll
+    for (int j = 0; j < CS_ROWS / 8; ++j) {
+      const int r = r0 + rl + 8 * j;
+      if (r < rows) {
+        float v[8];
+        load8<T>(M + (size_t)r * ld + c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += v[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[rl][cl + i] = s[i];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+    atomicAdd(out + cc, t);
+  }
+}
+
 // ---------------------------------------------------------------- head backward
 // dh2[t][n][u] = sum_o dY[t][n][o] * Wh[o][u],   dY[t][n][o] = dout[bo][o][fo][t-la] (0 for t < la)
 // one wave = 16 rows; A fragment gathered from dout (K = O <= 32), B = WhT packed [Hd][32].
@@ -90,24 +128,25 @@ __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restric
 // dWh[o][u] += sum_rows dY[row][o] * h2[row][u];  dbh[o] += sum_rows dY[row][o]
 // block = (t, chunk of 64 rows); thread u (blockDim = Hd rounded up to 64)
 constexpr int HB_ROWS = 64;
-template <typename T>
+template <typename T, int OP>
 __global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __restrict__ h2, float* __restrict__ dWh,
                                   float* __restrict__ dbh, long Nseq, int Tn, int la, int Hd, int O, int Fo) {
   // one workgroup = frame t and every gridDim.x-th chunk of 64 sequences: the O*Hd partial sums stay in registers over
   // all its chunks and reach memory with ONE atomic each (one workgroup per chunk meant 16k workgroups x 3840 atomics on
-  // the same 3840 addresses)
-  __shared__ float dy[HB_ROWS][33];
+  // the same 3840 addresses).  OP = O rounded up to 8/16/32: the dY row is read from LDS as broadcast float4s, so a row
+  // costs OP/4 LDS instructions + OP FMAs per thread (with OP fixed at 32 the LDS issue rate bounded the kernel)
+  __shared__ __attribute__((aligned(16))) float dy[HB_ROWS][OP];
   const int t = la + blockIdx.y;
   const int To = Tn - la;
   const int u = threadIdx.x;
-  float acc[32];
+  float acc[OP];
 #pragma unroll
-  for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+  for (int o = 0; o < OP; ++o) acc[o] = 0.f;
   float bsum = 0.f;
   for (long n0 = (long)blockIdx.x * HB_ROWS; n0 < Nseq; n0 += (long)gridDim.x * HB_ROWS) {
     __syncthreads();
-    for (int e = threadIdx.x; e < HB_ROWS * 32; e += blockDim.x) {
-      const int r = e / 32, o = e % 32;
+    for (int e = threadIdx.x; e < HB_ROWS * OP; e += blockDim.x) {
+      const int r = e / OP, o = e % OP;
       const long nn = n0 + r;
       float v = 0.f;
       if (nn < Nseq && o < O) {
@@ -118,23 +157,38 @@ __global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __res
     }
     __syncthreads();
     if (u < Hd) {
-      for (int r = 0; r < HB_ROWS; ++r) {
-        const long nn = n0 + r;
-        if (nn >= Nseq) break;
-        const float hv = to_f32<T>(h2[((size_t)t * Nseq + nn) * Hd + u]);
+      const int nr = Nseq - n0 < HB_ROWS ? (int)(Nseq - n0) : HB_ROWS;
+      const T* hp = h2 + ((size_t)t * Nseq + n0) * Hd + u;
+#pragma unroll 4
+      for (int r = 0; r < nr; ++r) {
+        const float hv = to_f32<T>(hp[(size_t)r * Hd]);
 #pragma unroll
-        for (int o = 0; o < 32; ++o) acc[o] += dy[r][o] * hv;
+        for (int o4 = 0; o4 < OP / 4; ++o4) {
+          const float4 d = *reinterpret_cast<const float4*>(&dy[r][4 * o4]);
+          acc[4 * o4] += d.x * hv;
+          acc[4 * o4 + 1] += d.y * hv;
+          acc[4 * o4 + 2] += d.z * hv;
+          acc[4 * o4 + 3] += d.w * hv;
+        }
       }
     }
-    if (threadIdx.x < 32 && threadIdx.x < O)
+    if (threadIdx.x < OP && threadIdx.x < O)
       for (int r = 0; r < HB_ROWS; ++r) bsum += dy[r][threadIdx.x];
   }
   if (u < Hd) {
 #pragma unroll
-    for (int o = 0; o < 32; ++o)
+    for (int o = 0; o < OP; ++o)
       if (o < O) atomicAdd(dWh + (size_t)o * Hd + u, acc[o]);
   }
-  if (threadIdx.x < 32 && threadIdx.x < O) atomicAdd(dbh + threadIdx.x, bsum);
+  if (threadIdx.x < OP && threadIdx.x < O) atomicAdd(dbh + threadIdx.x, bsum);
+}
+
+template <typename T>
+static void launch_head_bwd_w(dim3 grid, int bw, hipStream_t s, const float* dout, const T* h2, float* dWh, float* dbh, long Nseq,
+                              int Tn, int la, int Hd, int O, int Fo) {
+  if (O <= 8) hipLaunchKernelGGL((head_bwd_w_kernel<T, 8>), grid, dim3(bw), 0, s, dout, h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
+  else if (O <= 16) hipLaunchKernelGGL((head_bwd_w_kernel<T, 16>), grid, dim3(bw), 0, s, dout, h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
+  else hipLaunchKernelGGL((head_bwd_w_kernel<T, 32>), grid, dim3(bw), 0, s, dout, h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
 }
 
 // ---------------------------------------------------------------- sub-band staging backward
@@ -279,9 +333,19 @@ int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long
 int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
                 void* stream) {
   if (!M || !out || rows <= 0 || cols <= 0) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = prec == NPPC_PREC_BF16 ? 2 : 4;
+  if (ld >= (long)round_up(cols, 8) && ld % 8 == 0 && sM % 8 == 0 && ((uintptr_t)M) % 16 == 0 && (ld * esz) % 16 == 0) {
+    dim3 grid(ceil_div(cols, 256), ceil_div(rows, CS_ROWS), batch);
+    if (prec == NPPC_PREC_BF16)
+      hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, out, rows, cols, ld, sM, sOut);
+    else
+      hipLaunchKernelGGL(colsum8_kernel<float>, grid, dim3(256), 0, s, (const float*)M, out, rows, cols, ld, sM, sOut);
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
   const int rpb = 128;
   dim3 grid(ceil_div(cols, 256), ceil_div(rows, rpb), batch);
-  hipStream_t s = (hipStream_t)stream;
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, out, rows, cols, ld, sM, sOut, rpb);
   else
@@ -301,12 +365,11 @@ int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h
   if (prec == NPPC_PREC_BF16) {
     hipLaunchKernelGGL(head_bwd_dh_kernel<bf16_t>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const bf16_t*)whT,
                        (bf16_t*)dh2, Nseq, Tn, la, Hd, O, Fo);
-    hipLaunchKernelGGL(head_bwd_w_kernel<bf16_t>, gw, dim3(bw), 0, s, dout, (const bf16_t*)h2, dWh, dbh, Nseq, Tn, la, Hd, O,
-                       Fo);
+    launch_head_bwd_w<bf16_t>(gw, bw, s, dout, (const bf16_t*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
   } else {
     hipLaunchKernelGGL(head_bwd_dh_kernel<float>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const float*)whT,
                        (float*)dh2, Nseq, Tn, la, Hd, O, Fo);
-    hipLaunchKernelGGL(head_bwd_w_kernel<float>, gw, dim3(bw), 0, s, dout, (const float*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
+    launch_head_bwd_w<float>(gw, bw, s, dout, (const float*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
   }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;

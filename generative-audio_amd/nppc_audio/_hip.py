@@ -98,6 +98,7 @@ SIGS = {
     "nppc_tcn_dwconv": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_gn_apply": [I, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_pack_matrix": [I, P, P, I, I, I, I, I, P],
+    "nppc_pack_matrix_batched": [I, P, P, I, I, I, I, I, I, I, L, L, L, L, P],
     "nppc_subband_mean": [I, P, I, P, I, L, P, P, I, I, I, I, I, P],
     "nppc_subband_stage": [I, P, I, P, I, L, P, P, I, I, I, I, I, I, I, I, P],
     "nppc_sb_head": [I, P, P, P, P, L, I, I, I, I, I, P],
@@ -107,6 +108,7 @@ SIGS = {
     "nppc_gs_bwd_solve": [P, P, P, P, I, I, I, P],
     "nppc_loss_solve": [P, P, P, P, P, P, P, P, P, P, I, I, P],
     "nppc_loss_bwd_coef": [P, P, P, F, F, P, I, I, P],
+    "nppc_loss_bwd_coef_dev": [P, P, P, P, F, F, P, I, I, P],
     "nppc_transpose": [I, P, P, I, I, L, L, L, L, I, I, P],
     "nppc_colsum": [I, P, P, I, I, L, L, L, I, P],
     "nppc_sb_head_bwd": [I, P, P, P, P, P, P, L, I, I, I, I, I, P],

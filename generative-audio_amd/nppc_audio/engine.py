@@ -138,25 +138,32 @@ class FSNEngine:
             return
         s = H.stream()
         C, ldC, ldF = self.C, self.ldC, self.ldF
-        for z, br in enumerate(BRANCHES):
+        # the 8 TCN blocks x 3 branches are equally shaped and sit at constant strides in the flat buffer: one launch each
+        lay = self.fp.off["fb_model.sequence_model.1.conv1x1.weight"][0] - self.fp.off["fb_model.sequence_model.0.conv1x1.weight"][0]
+        brs = self.fp.branch_stride()
+        if self.packed_version is None:            # first pack: check the constant-stride assumption once
             for i in range(8):
-                pre = f"fb_model{br}.sequence_model.{i}"
-                H.call("nppc_pack_matrix", self.prec, self.p(pre + ".conv1x1.weight"), self.W1p[i, z], TCN_HIDDEN, C,
-                       TCN_HIDDEN, ldC, 0, s)
-                H.call("nppc_pack_matrix", self.prec, self.p(pre + ".sconv.weight"), self.W2p[i, z], C, TCN_HIDDEN, ldC,
-                       TCN_HIDDEN, 0, s)
+                for z, br in enumerate(BRANCHES):
+                    for leaf in ("conv1x1.weight", "sconv.weight"):
+                        assert (self.fp.off[f"fb_model{br}.sequence_model.{i}.{leaf}"][0]
+                                == self.fp.off[f"fb_model.sequence_model.0.{leaf}"][0] + i * lay + z * brs)
+        w1, w2 = self.p("fb_model.sequence_model.0.conv1x1.weight"), self.p("fb_model.sequence_model.0.sconv.weight")
+
+        def packed(src, dst, N, K, Npad, ldd, tr):
+            H.call("nppc_pack_matrix_batched", self.prec, src, dst, N, K, Npad, ldd, tr, 8, 3, lay, brs, dst.stride(0),
+                   dst.stride(1), s)
+
+        packed(w1, self.W1p, TCN_HIDDEN, C, TCN_HIDDEN, ldC, 0)
+        packed(w2, self.W2p, C, TCN_HIDDEN, ldC, TCN_HIDDEN, 0)
+        for z, br in enumerate(BRANCHES):
             H.call("nppc_pack_matrix", self.prec, self.p(f"fb_model{br}.fc_output_layer.weight"), self.Wfcp[z], self.F, C,
                    ldF, ldC, 0, s)
         H.call("nppc_pack_matrix", self.prec, self.p("sb_model.fc_output_layer.weight"), self.Whp, self.O, self.Hd,
                self.Opad, self.Hd, 0, s)
         if self.trainable:
+            packed(w1, self.W1T, C, TCN_HIDDEN, ldC, TCN_HIDDEN, 1)
+            packed(w2, self.W2T, TCN_HIDDEN, C, TCN_HIDDEN, ldC, 1)
             for z, br in enumerate(BRANCHES):
-                for i in range(8):
-                    pre = f"fb_model{br}.sequence_model.{i}"
-                    H.call("nppc_pack_matrix", self.prec, self.p(pre + ".conv1x1.weight"), self.W1T[i, z], C, TCN_HIDDEN,
-                           ldC, TCN_HIDDEN, 1, s)
-                    H.call("nppc_pack_matrix", self.prec, self.p(pre + ".sconv.weight"), self.W2T[i, z], TCN_HIDDEN, C,
-                           TCN_HIDDEN, ldC, 1, s)
                 H.call("nppc_pack_matrix", self.prec, self.p(f"fb_model{br}.fc_output_layer.weight"), self.WfcT[z], C,
                        self.F, ldC, ldF, 1, s)
             H.call("nppc_pack_matrix", self.prec, self.p("sb_model.fc_output_layer.weight"), self.WhT, self.Hd, self.O,

@@ -8,6 +8,21 @@ def _z(B, KV, dev):
     return torch.zeros(B, KV, KV, 2, dtype=torch.float64, device=dev)
 
 
+_EYES = {}
+
+
+def _eye(B, K, dev):
+    """constant complex identity [B,K,K,2] (fp64), built once per shape: index_put in every backward cost three launches"""
+    key = (B, K, str(dev))
+    e = _EYES.get(key)
+    if e is None:
+        e = _z(B, K, dev)
+        idx = torch.arange(K, device=dev)
+        e[:, idx, idx, 0] = 1.0
+        _EYES[key] = e
+    return e
+
+
 class GramSchmidtCRM(torch.autograd.Function):
     """pc_wrapper.py:8-44 on [B,K,2,F,T] (w_hat detached, conj-coefficient quirk, no epsilon)."""
 
@@ -38,9 +53,7 @@ class GramSchmidtCRM(torch.autograd.Function):
         H.call("nppc_gram", g, x, None, None, P, B, K, N, s)
         D = torch.empty_like(G)
         H.call("nppc_gs_bwd_solve", G, P, Ch, D, B, K, K, s)
-        eye = _z(B, K, x.device)
-        idx = torch.arange(K, device=x.device)
-        eye[:, idx, idx, 0] = 1.0
+        eye = _eye(B, K, x.device)
         dx = torch.empty_like(x)
         H.call("nppc_combine", g, eye, x, D, None, None, dx, B, K, N, s)
         return dx
@@ -84,10 +97,13 @@ class NPPCLoss(torch.autograd.Function):
         B, K = w.shape[:2]
         N = w[0, 0, 0].numel()
         s = H.stream()
-        go = float(g_obj) if g_obj is not None else 0.0
         grec = g_rec.contiguous().float() if g_rec is not None else None
         M1 = torch.empty(B, K + 1, K + 1, 2, dtype=torch.float64, device=w.device)
-        H.call("nppc_loss_bwd_coef", coefA, coefE, grec, go / B, go * ctx.lam / (B * K), M1, B, K, s)
+        if g_obj is None:
+            H.call("nppc_loss_bwd_coef", coefA, coefE, grec, 0.0, 0.0, M1, B, K, s)
+        else:       # the upstream scalar stays on the device: float(g_obj) here stalled the host ~1 ms every step
+            H.call("nppc_loss_bwd_coef_dev", coefA, coefE, grec, g_obj.contiguous().float(), 1.0 / B, ctx.lam / (B * K), M1,
+                   B, K, s)
         dw = torch.empty_like(w)
         H.call("nppc_combine", w, M1, None, None, gt, pred, dw, B, K, N, s)
         return dw, None, None, None, None, None

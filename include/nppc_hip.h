@@ -76,6 +76,10 @@ int nppc_gemm_tn_splitk_batched(const void* A, long lda, long sA, const void* B,
 int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
                              int ksplit, int Wp, int shift_a, void* stream);
 int nppc_pack_matrix(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, void* stream);
+/* the same for an n_a x n_b grid of equally shaped matrices at constant strides (elements) in ONE launch: the 8 TCN blocks
+ * x 3 full-band branches of a FullSubNet+ keep their parameters at constant offsets in the flat parameter buffer */
+int nppc_pack_matrix_batched(int prec, const float* src, void* dst, int N, int K, int Npad, int ldd, int transpose, int n_a,
+                             int n_b, long src_stride_a, long src_stride_b, long dst_stride_a, long dst_stride_b, void* stream);
 int nppc_tcn_dwconv(int prec, const void* in, void* out, const double* st1, double* st2, const float* gamma,
                     const float* beta, const float* wd, const float* bd, const float* slope2, int B, int Cc, int ld, int Tp,
                     int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream);
@@ -167,6 +171,10 @@ int nppc_loss_solve_eps(const double* G, float* err_norm, float* proj_re, float*
                         void* stream);
 int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* grec, float gobj_over_B, float gsm, double* M1,
                        int B, int K, void* stream);
+/* the same with the upstream gradient of the objective read from DEVICE memory (gobj, one float): the coefficients are
+ * (gobj * inv_B, gobj * sm_weight); autograd's backward then never reads a scalar back to the host */
+int nppc_loss_bwd_coef_dev(const double* coefA, const double* coefE, const float* grec, const float* gobj, float inv_B,
+                           float sm_weight, double* M1, int B, int K, void* stream);
 
 /* ---- optimizer: torch.optim.Adam (nppc_audio/trainer.py:64-69,102-104) -------------------------------------- */
 int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
