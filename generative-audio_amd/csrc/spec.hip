@@ -36,30 +36,34 @@ struct TsseW {
 // mean_t(conv_ks(norm x))[c] = bias + ns/(Tp-ks+1) * sum_k w[c][k] * (rowsum - prefix(k) - suffix(ks-1-k)).
 // Outputs: scale[b][c] = ns_b * s[b][c];  saved for backward: ns[B], pre[B][C][3], sq[B][C], h1[B][C2], sg[B][C].
 constexpr int TSSE_MAXC = 1024;
-__global__ __launch_bounds__(256) void tsse_fwd_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
+// blockDim = C rounded up to 64 (<= 1024): with 256 threads a C = 257 map took two trips through every per-channel loop,
+// the second for ONE channel
+__global__ __launch_bounds__(1024) void tsse_fwd_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
                                                        TsseW w, float* __restrict__ scale, float* __restrict__ ns_out,
                                                        float* __restrict__ pre_out, float* __restrict__ sq_out,
                                                        float* __restrict__ h1_out, float* __restrict__ sg_out, int C, int C2,
                                                        int T, int la) {
-  __shared__ double red[4];
+  __shared__ double red[16];
   __shared__ float sq[TSSE_MAXC];
   __shared__ float h1[TSSE_MAXC / 2];
   __shared__ float ns_s;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Tp = T + la;
   double part = 0.0;
-  for (int c = tid; c < C; c += 256) part += rowsum[(size_t)b * C + c];
+  for (int c = tid; c < C; c += blockDim.x) part += rowsum[(size_t)b * C + c];
   part = wave_sum(part);
   if ((tid & 63) == 0) red[tid >> 6] = part;
   __syncthreads();
   if (tid == 0) {
-    const float mu = (float)((red[0] + red[1] + red[2] + red[3]) / ((double)C * Tp));
+    double tot_all = 0.0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot_all += red[wv];
+    const float mu = (float)(tot_all / ((double)C * Tp));
     ns_s = 1.0f / (mu + 1e-5f);
     if (ns_out) ns_out[b] = ns_s;
   }
   __syncthreads();
   const float ns = ns_s;
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += blockDim.x) {
     const float* xr = x + ((size_t)b * C + c) * T;
     const double tot = rowsum[(size_t)b * C + c];
     float acc = w.fcb[0];
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void tsse_fwd_kernel(const float* __restrict__
     if (sq_out) sq_out[(size_t)b * C + c] = acc;
   }
   __syncthreads();
-  for (int j = tid; j < C2; j += 256) {
+  for (int j = tid; j < C2; j += blockDim.x) {
     float a = w.b1[j];
     const float* wr = w.w1 + (size_t)j * C;
     for (int c = 0; c < C; ++c) a += wr[c] * sq[c];
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void tsse_fwd_kernel(const float* __restrict__
     if (h1_out) h1_out[(size_t)b * C2 + j] = a;
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += blockDim.x) {
     float a = w.b2[c];
     const float* wr = w.w2 + (size_t)c * C2;
     for (int j = 0; j < C2; ++j) a += wr[j] * h1[j];
@@ -128,17 +132,34 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
 
 // ---------------------------------------------------------------- TSSE backward (direction net: attention weights train)
 // X0[b][t][coff+c] = x[b][c][t] * ns_b * sg[b][c]  ->  dsg[b][c] = ns_b * sum_t dX0[b][t][coff+c] * x[b][c][t]
+// one workgroup = 64 channels x 64 frames of one sample: x is read along t, dX0 along c (both coalesced), multiplied
+// through an LDS tile; partial sums over the frame chunk go to the ZEROED dsg with one atomic per channel
 template <typename T>
 __global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ dX0, const float* __restrict__ x,
                                                           const float* __restrict__ ns, float* __restrict__ dsg, int C, int Tn,
                                                           int Tp, int ld, int coff) {
-  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float* xr = x + ((size_t)b * C + c) * Tn;
-  const T* dp = dX0 + (size_t)b * Tp * ld + coff + c;
+  __shared__ float xt[64][65];
+  __shared__ float part[4][64];
+  const int b = blockIdx.z, c0 = blockIdx.x * 64, t0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int cc = e / 64, tt = e % 64;
+    xt[cc][tt] = (c0 + cc < C && t0 + tt < Tn) ? x[((size_t)b * C + c0 + cc) * Tn + t0 + tt] : 0.f;
+  }
+  __syncthreads();
+  const int cl = tid & 63, tl = tid >> 6;
   float s = 0.f;
-  for (int t = 0; t < Tn; ++t) s += to_f32<T>(dp[(size_t)t * ld]) * xr[t];
-  dsg[(size_t)b * C + c] = ns[b] * s;
+  if (c0 + cl < C) {
+    const T* dp = dX0 + (size_t)b * Tp * ld + coff + c0 + cl;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int tt = tl + 4 * k;
+      if (t0 + tt < Tn) s += to_f32<T>(dp[(size_t)(t0 + tt) * ld]) * xt[cl][tt];
+    }
+  }
+  part[tl][cl] = s;
+  __syncthreads();
+  if (tid < 64 && c0 + tid < C)
+    atomicAdd(dsg + (size_t)b * C + c0 + tid, ns[b] * (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]));
 }
 
 struct TsseG {
@@ -149,7 +170,7 @@ struct TsseG {
 
 // one workgroup per sample: backprop dsg through sigmoid/fc2/relu/fc1/feature_concate_fc/relu/conv-means;
 // parameter gradients are shared by all samples (and by the noisy/enhanced calls) -> fp32 atomics
-__global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
+__global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
                                                            TsseW w, TsseG g, const float* __restrict__ ns_in,
                                                            const float* __restrict__ pre, const float* __restrict__ sq,
                                                            const float* __restrict__ h1, const float* __restrict__ sg,
@@ -161,14 +182,14 @@ __global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restri
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Tp = T + la;
   const float ns = ns_in[b];
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += blockDim.x) {
     const float s = sg[(size_t)b * C + c];
     const float d = dsg[(size_t)b * C + c] * s * (1.f - s);
     da2[c] = d;
     da2_ws[(size_t)b * C + c] = d;          // fc2 / fc1 weight gradients: tsse_bwd_outer_kernel (sum over samples)
   }
   __syncthreads();
-  for (int j = tid; j < C2; j += 256) {
+  for (int j = tid; j < C2; j += blockDim.x) {
     float a = 0.f;
     for (int c = 0; c < C; ++c) a += w.w2[(size_t)c * C2 + j] * da2[c];
     a = h1[(size_t)b * C2 + j] > 0.f ? a : 0.f;
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(256) void tsse_bwd_mlp_kernel(const float* __restri
   }
   __syncthreads();
   float fsum[3] = {0.f, 0.f, 0.f}, bsum = 0.f;
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += blockDim.x) {
     float a = 0.f;
     for (int j = 0; j < C2; ++j) a += w.w1[(size_t)j * C + c] * da1[j];
     dsq[c] = a;
@@ -255,7 +276,8 @@ int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsu
                   int ld, int coff, void* stream) {
   if (!dX0 || !x || !rowsum || !dsg_ws || B <= 0 || C > TSSE_MAXC) return NPPC_EBADARG;
   hipStream_t s = (hipStream_t)stream;
-  dim3 g1(ceil_div(C, 256), B);
+  dim3 g1(ceil_div(C, 64), ceil_div(T, 64), B);
+  if (hipMemsetAsync(dsg_ws, 0, sizeof(float) * (size_t)B * C, s) != hipSuccess) return NPPC_ELAUNCH;
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
   else
@@ -265,7 +287,8 @@ int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsu
   // dsg_ws holds B * (2 C + C/2) floats: dsg [B][C] | da2 [B][C] | da1 [B][C/2]
   float* da2_ws = dsg_ws + (size_t)B * C;
   float* da1_ws = da2_ws + (size_t)B * C;
-  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(256), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, da2_ws, da1_ws,
+  const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(nt), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, da2_ws, da1_ws,
                      C, C / 2, T, look_ahead);
   const int C2 = C / 2;
   hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256)), dim3(256), 0, s, da2_ws, da1_ws, h1, sq, g,
@@ -289,7 +312,8 @@ int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const 
   if (!x || !rowsum || !scale || B <= 0 || C <= 0 || C > TSSE_MAXC) return NPPC_EBADARG;
   if (ks0 > T || ks1 > T || ks2 > T) return NPPC_EUNSUPPORTED;
   TsseW w{{cw0, cw1, cw2}, {cb0, cb1, cb2}, {ks0, ks1, ks2}, fcw, fcb, w1, b1, w2, b2};
-  hipLaunchKernelGGL(tsse_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, rowsum, w, scale, ns, pre, sq, h1, sg,
+  const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
+  hipLaunchKernelGGL(tsse_fwd_kernel, dim3(B), dim3(nt), 0, (hipStream_t)stream, x, rowsum, w, scale, ns, pre, sq, h1, sg,
                      C, C / 2, T, look_ahead);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void gn_prelu_bwd_kernel(const T* __restrict__
   const float inva = 1.f / a;
   float g8[8];
   loadf8(gamma + c8, g8);
+  constexpr int UNR = 1;      // pure streaming (2 loads + 1 store per row): occupancy hides the latency, batching rows only costs registers
   if (tl < rpi) {
     const int tend = (blockIdx.x + 1) * RPB < Tp ? (blockIdx.x + 1) * RPB : Tp;
     for (int tb = blockIdx.x * RPB + tl; tb < tend; tb += UNR * rpi) {
