@@ -127,17 +127,18 @@ __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restric
 
 // dWh[o][u] += sum_rows dY[row][o] * h2[row][u];  dbh[o] += sum_rows dY[row][o]
 // block = (t, chunk of 64 rows); thread u (blockDim = Hd rounded up to 64)
-constexpr int HB_ROWS = 64, HB_TT = 8;
+constexpr int HB_ROWS = 64;
 template <typename T, int OP>
 __global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __restrict__ h2, float* __restrict__ dWh,
                                   float* __restrict__ dbh, long Nseq, int Tn, int la, int Hd, int O, int Fo) {
-  // one workgroup = HB_TT consecutive frames and every gridDim.x-th chunk of 64 sequences: the O*Hd partial sums stay in
-  // registers over all its chunks and reach memory with ONE atomic each (one workgroup per chunk meant 16k workgroups x
-  // 3840 atomics on the same 3840 addresses).  dout is [.., To] with t innermost: gathering HB_TT frames at a time reads
-  // 32-byte runs instead of single floats.  OP = O rounded up to 8/16/32: a dY row is read from LDS as broadcast float4s,
-  // OP/4 LDS instructions + OP FMAs per thread and row (with OP fixed at 32 the LDS issue rate bounded the kernel)
-  __shared__ __attribute__((aligned(16))) float dy[HB_TT][HB_ROWS][OP];
-  const int t0 = la + blockIdx.y * HB_TT;
+  // one workgroup = frame t and every gridDim.x-th chunk of 64 sequences: the O*Hd partial sums stay in registers over
+  // all its chunks and reach memory with ONE atomic each (one workgroup per chunk meant 16k workgroups x 3840 atomics on
+  // the same 3840 addresses).  OP = O rounded up to 8/16/32: the dY row is read from LDS as broadcast float4s, so a row
+  // costs OP/4 LDS instructions + OP FMAs per thread (with OP fixed at 32 the LDS issue rate bounded the kernel).
+  // (Gathering 8 frames per staging round -- 32-byte runs of dout instead of single floats -- needed 32 KB of LDS and
+  // halved the workgroups: 0.62 -> 1.1 ms, the 2-byte h2 loads lost their latency cover.)
+  __shared__ __attribute__((aligned(16))) float dy[HB_ROWS][OP];
+  const int t = la + blockIdx.y;
   const int To = Tn - la;
   const int u = threadIdx.x;
   float acc[OP];
@@ -146,38 +147,35 @@ __global__ void head_bwd_w_kernel(const float* __restrict__ dout, const T* __res
   float bsum = 0.f;
   for (long n0 = (long)blockIdx.x * HB_ROWS; n0 < Nseq; n0 += (long)gridDim.x * HB_ROWS) {
     __syncthreads();
-    for (int e = threadIdx.x; e < HB_TT * HB_ROWS * OP; e += blockDim.x) {
-      const int tt = e % HB_TT, o = (e / HB_TT) % OP, r = e / (HB_TT * OP);
+    for (int e = threadIdx.x; e < HB_ROWS * OP; e += blockDim.x) {
+      const int r = e / OP, o = e % OP;
       const long nn = n0 + r;
       float v = 0.f;
-      if (nn < Nseq && o < O && t0 + tt < Tn) {
+      if (nn < Nseq && o < O) {
         const long bo = nn / Fo, fo = nn % Fo;
-        v = dout[((bo * O + o) * Fo + fo) * To + (t0 + tt - la)];
+        v = dout[((bo * O + o) * Fo + fo) * To + (t - la)];
       }
-      dy[tt][r][o] = v;
+      dy[r][o] = v;
     }
     __syncthreads();
     if (u < Hd) {
       const int nr = Nseq - n0 < HB_ROWS ? (int)(Nseq - n0) : HB_ROWS;
-      for (int tt = 0; tt < HB_TT && t0 + tt < Tn; ++tt) {
-        const T* hp = h2 + ((size_t)(t0 + tt) * Nseq + n0) * Hd + u;
+      const T* hp = h2 + ((size_t)t * Nseq + n0) * Hd + u;
 #pragma unroll 4
-        for (int r = 0; r < nr; ++r) {
-          const float hv = to_f32<T>(hp[(size_t)r * Hd]);
+      for (int r = 0; r < nr; ++r) {
+        const float hv = to_f32<T>(hp[(size_t)r * Hd]);
 #pragma unroll
-          for (int o4 = 0; o4 < OP / 4; ++o4) {
-            const float4 d = *reinterpret_cast<const float4*>(&dy[tt][r][4 * o4]);
-            acc[4 * o4] += d.x * hv;
-            acc[4 * o4 + 1] += d.y * hv;
-            acc[4 * o4 + 2] += d.z * hv;
-            acc[4 * o4 + 3] += d.w * hv;
-          }
+        for (int o4 = 0; o4 < OP / 4; ++o4) {
+          const float4 d = *reinterpret_cast<const float4*>(&dy[r][4 * o4]);
+          acc[4 * o4] += d.x * hv;
+          acc[4 * o4 + 1] += d.y * hv;
+          acc[4 * o4 + 2] += d.z * hv;
+          acc[4 * o4 + 3] += d.w * hv;
         }
       }
     }
     if (threadIdx.x < OP && threadIdx.x < O)
-      for (int tt = 0; tt < HB_TT; ++tt)
-        for (int r = 0; r < HB_ROWS; ++r) bsum += dy[tt][r][threadIdx.x];
+      for (int r = 0; r < HB_ROWS; ++r) bsum += dy[r][threadIdx.x];
   }
   if (u < Hd) {
 #pragma unroll
@@ -364,7 +362,7 @@ int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h
   hipStream_t s = (hipStream_t)stream;
   const long tiles = ((Nseq + 15) / 16) * Tn;
   const int chunks = ceil_div(Nseq, HB_ROWS);
-  dim3 gw(chunks < 16 ? chunks : 16, ceil_div(Tn - la, HB_TT));
+  dim3 gw(chunks < 4 ? chunks : 4, Tn - la);
   const int bw = round_up(Hd, 64);
   if (prec == NPPC_PREC_BF16) {
     hipLaunchKernelGGL(head_bwd_dh_kernel<bf16_t>, dim3(ceil_div(tiles, 4)), dim3(256), 0, s, dout, (const bf16_t*)whT,
