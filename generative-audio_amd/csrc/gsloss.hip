@@ -217,6 +217,98 @@ __global__ void gs_bwd_solve_kernel(const double* __restrict__ Gall, const doubl
   }
 }
 
+// The same two solves with K a compile-time constant (KV may exceed K): every loop unrolls, the K x K coefficient
+// matrices live in registers -- the generic kernels index them dynamically, i.e. through scratch memory (98 / 73 us per
+// call for 32 5 x 5 problems; the arithmetic is microseconds).  Same operation order as the generic kernels.
+template <int KT>
+__device__ __forceinline__ cd gdot_t(const cd (&a)[KT], const cd (&bvec)[KT], const cd (&G)[KT][KT]) {
+  cd s{0, 0};
+#pragma unroll
+  for (int m = 0; m < KT; ++m)
+#pragma unroll
+    for (int n = 0; n < KT; ++n) s = cadd(s, cmul(cmul(cconj(a[m]), bvec[n]), G[m][n]));
+  return s;
+}
+
+template <int KT>
+__global__ __launch_bounds__(64) void gs_solve_t_kernel(const double* __restrict__ Gall, double* __restrict__ Call, double* __restrict__ Chall, int B,
+                                  int KV) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* Gp = Gall + (size_t)b * KV * KV * 2;
+  cd G[KT][KT], C[KT][KT], Ch[KT][KT];
+#pragma unroll
+  for (int m = 0; m < KT; ++m)
+#pragma unroll
+    for (int n = 0; n < KT; ++n) G[m][n] = {Gp[(m * KV + n) * 2], Gp[(m * KV + n) * 2 + 1]};
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+#pragma unroll
+    for (int m = 0; m < KT; ++m) C[i][m] = {m == i ? 1.0 : 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      const cd sj = gdot_t<KT>(C[i], Ch[j], G);
+#pragma unroll
+      for (int m = 0; m < KT; ++m) C[i][m] = csub(C[i][m], cmul(sj, Ch[j][m]));
+    }
+    const double nrm = sqrt(gdot_t<KT>(C[i], C[i], G).r);
+#pragma unroll
+    for (int m = 0; m < KT; ++m) Ch[i][m] = {C[i][m].r / nrm, C[i][m].i / nrm};
+  }
+  double* Co = Call + (size_t)b * KV * KV * 2;
+  double* Cho = Chall + (size_t)b * KV * KV * 2;
+  for (int e = 0; e < KV * KV * 2; ++e) { Co[e] = 0.0; Cho[e] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int m = 0; m < KT; ++m) {
+      Co[(i * KV + m) * 2] = C[i][m].r;
+      Co[(i * KV + m) * 2 + 1] = C[i][m].i;
+      Cho[(i * KV + m) * 2] = Ch[i][m].r;
+      Cho[(i * KV + m) * 2 + 1] = Ch[i][m].i;
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(64) void gs_bwd_solve_t_kernel(const double* __restrict__ Gall, const double* __restrict__ Pall,
+                                      const double* __restrict__ Chall, double* __restrict__ Dall, int B, int KV) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* Gp = Gall + (size_t)b * KV * KV * 2;
+  const double* P = Pall + (size_t)b * KV * KV * 2;
+  const double* Chp = Chall + (size_t)b * KV * KV * 2;
+  double* Do = Dall + (size_t)b * KV * KV * 2;
+  cd G[KT][KT], Ch[KT][KT];
+#pragma unroll
+  for (int m = 0; m < KT; ++m)
+#pragma unroll
+    for (int n = 0; n < KT; ++n) {
+      G[m][n] = {Gp[(m * KV + n) * 2], Gp[(m * KV + n) * 2 + 1]};
+      Ch[m][n] = {Chp[(m * KV + n) * 2], Chp[(m * KV + n) * 2 + 1]};
+    }
+  for (int e = 0; e < KV * KV * 2; ++e) Do[e] = 0.0;
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    cd d[KT], Pi[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m) {
+      d[m] = {0, 0};
+      Pi[m] = {P[(i * KV + m) * 2], P[(i * KV + m) * 2 + 1]};
+    }
+#pragma unroll
+    for (int j = i - 1; j >= 0; --j) {
+      cd sj{0, 0};
+#pragma unroll
+      for (int n = 0; n < KT; ++n) sj = cadd(sj, cmul(Ch[j][n], Pi[n]));
+      sj = cadd(sj, gdot_t<KT>(d, Ch[j], G));
+#pragma unroll
+      for (int m = 0; m < KT; ++m) d[m] = csub(d[m], cmul(sj, Ch[j][m]));
+    }
+#pragma unroll
+    for (int m = 0; m < KT; ++m) { Do[(i * KV + m) * 2] = d[m].r; Do[(i * KV + m) * 2 + 1] = d[m].i; }
+  }
+}
+
 // Loss scalars from the Gram of [w_0..w_{K-1}, e] (KV = K+1), trainer.py:269-298.
 // Also the backward coefficients: dL/dw_i = a_i w_i + b_i e  with upstream weights
 //   dL/d(reconst_b) = gr[b] (+ gobj/B folded in by the host), dL/d(sm_bi) = gs (= gobj*lambda/(B*K)).
@@ -343,14 +435,32 @@ int nppc_combine(const float* a, const double* M1, const float* b, const double*
 
 int nppc_gs_solve(const double* G, double* C, double* Ch, int B, int K, int KV, void* stream) {
   if (!G || !C || !Ch || K > KMAX || KV < K) return NPPC_EBADARG;
-  hipLaunchKernelGGL(gs_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, C, Ch, B, K, KV);
+  const dim3 grid(ceil_div(B, 64));
+  hipStream_t s = (hipStream_t)stream;
+  switch (K) {      // register-resident specialisations for the direction counts in use (K = 2..6, 8)
+    case 2: hipLaunchKernelGGL(gs_solve_t_kernel<2>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
+    case 3: hipLaunchKernelGGL(gs_solve_t_kernel<3>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
+    case 4: hipLaunchKernelGGL(gs_solve_t_kernel<4>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
+    case 5: hipLaunchKernelGGL(gs_solve_t_kernel<5>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
+    case 6: hipLaunchKernelGGL(gs_solve_t_kernel<6>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
+    default: hipLaunchKernelGGL(gs_solve_kernel, grid, dim3(64), 0, s, G, C, Ch, B, K, KV);
+  }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
 
 int nppc_gs_bwd_solve(const double* G, const double* P, const double* Ch, double* D, int B, int K, int KV, void* stream) {
   if (!G || !P || !Ch || !D || K > KMAX || KV < K) return NPPC_EBADARG;
-  hipLaunchKernelGGL(gs_bwd_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, P, Ch, D, B, K, KV);
+  const dim3 grid(ceil_div(B, 64));
+  hipStream_t s = (hipStream_t)stream;
+  switch (K) {
+    case 2: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<2>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
+    case 3: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<3>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
+    case 4: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<4>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
+    case 5: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<5>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
+    case 6: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<6>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
+    default: hipLaunchKernelGGL(gs_bwd_solve_kernel, grid, dim3(64), 0, s, G, P, Ch, D, B, K, KV);
+  }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
