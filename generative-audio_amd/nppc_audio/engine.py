@@ -5,6 +5,8 @@ one net (the frozen restorer: 3 input maps; the direction net: 6 maps, 2K output
 FullSubNet_Plus.forward (FullSubNet_plus/.../fullsubnet_plus.py:143-230) and
 MultiDirectionFullSubNet_Plus.forward (nppc_audio/networks.py:63-163) stage by stage.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,9 @@ EPI_PLAIN, EPI_PRELU_STATS, EPI_RESIDUAL, EPI_RELU, EPI_PLAIN_F32, EPI_MASK_POS 
 
 def rup(a, b):
     return (a + b - 1) // b * b
+
+
+TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 
 
 class FlatParams:
@@ -425,14 +430,34 @@ class FSNEngine:
         H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, s)
         H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, s)
         self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
-        dXa = ws("dXa", (3, B, Tp, ldC))
-        dXb = ws("dXb", (3, B, Tp, ldC))
+        # bf16: the 1x1-conv weight gradients run on the TN GEMM straight from the row-major activations (no transposes)
+        tn_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
+        if tn_ok:
+            # ... and on the side stream, behind the LSTM weight gradients: nothing downstream reads them before the
+            # optimizer, and the end of the main chain (TSSE backward, small kernels) leaves most CUs idle.  Their operands
+            # get one buffer per TCN block, so the main chain never waits for the side stream inside a step.
+            dXL = [ws(f"dX_{i}", (3, B, Tp, ldC)) for i in range(9)]
+            a2L = [ws(f"a2_{i}", (3, B, Tp, TCN_HIDDEN), zero=True) for i in range(8)]
+            h2L = [ws(f"h2b_{i}", (3, B, Tp, TCN_HIDDEN)) for i in range(8)]
+            dXa, dXb = dXL[8], dXL[7]
+        else:
+            dXa = ws("dXa", (3, B, Tp, ldC))
+            dXb = ws("dXb", (3, B, Tp, ldC))
+
+        def on_side(fn):
+            """run fn (which launches on the current stream) on the side stream once the main stream got here"""
+            if not TCN_WGRAD_ON_SIDE:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                fn()
+
         H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
                X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
         # ---- 6. TCN blocks in reverse
         sAct = B * Tp * TCN_HIDDEN
-        # bf16: the 1x1-conv weight gradients run on the TN GEMM straight from the row-major activations (no transposes)
-        tn_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
         Sgn = ws("Sgn", (3, B, 2), torch.float64)
@@ -442,19 +467,26 @@ class FSNEngine:
             dil = TCN_DILATIONS[i]
             st1, st2 = d["stats"][i, 0], d["stats"][i, 1]
             y1, y2, Xin = d["y1"][i], d["y2"][i], d["X"][i]
+            if tn_ok:
+                dXo, dXi, a2, h2b = dXL[i + 1], dXL[i], a2L[i], h2L[i]
+            else:
+                a2 = d["a2"]
             H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
             # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
-            H.call("nppc_tcn_gn_apply", prec, y2, d["a2"], st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), B,
+            H.call("nppc_tcn_gn_apply", prec, y2, a2, st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), B,
                    TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
             if tn_ok:
                 # row-major operands as they are: slab[k][c] = sum_r a2[r][k] * dXo[r][c] = dW2^T, transposed in the reduction
-                H.call("nppc_gemm_tn_splitk_batched", d["a2"], TCN_HIDDEN, sAct, dXo, ldC, R * ldC, slab2, ldC,
-                       S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, s)
-                H.call("nppc_reduce_slabs_t", slab2, S2, TCN_HIDDEN * ldC, ldC, self.g(pre + "sconv.weight"), TCN_HIDDEN, C,
-                       TCN_HIDDEN, S2 * TCN_HIDDEN * ldC, sP, 3, s)
+                def sconv_wgrad(a2=a2, dXo=dXo, dest=self.g(pre + "sconv.weight")):
+                    q = H.stream()
+                    H.call("nppc_gemm_tn_splitk_batched", a2, TCN_HIDDEN, sAct, dXo, ldC, R * ldC, slab2, ldC,
+                           S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, q)
+                    H.call("nppc_reduce_slabs_t", slab2, S2, TCN_HIDDEN * ldC, ldC, dest, TCN_HIDDEN, C, TCN_HIDDEN,
+                           S2 * TCN_HIDDEN * ldC, sP, 3, q)
+                on_side(sconv_wgrad)
             else:
                 H.call("nppc_transpose", prec, dXo, tA, R, ldC, ldC, R, R * ldC, sTA, 0, 3, s)
-                H.call("nppc_transpose", prec, d["a2"], tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
+                H.call("nppc_transpose", prec, a2, tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
                 self._wgrad(tA, R, sTA, tB, R, sTB, Cr, TCN_HIDDEN, R, S2, pre + "sconv.weight", TCN_HIDDEN, C, TCN_HIDDEN,
                             slab2, batch=3, sDst=sP)
             # dA2 = dXo W2
@@ -476,10 +508,13 @@ class FSNEngine:
             H.call("nppc_colsum", prec, h2b, self.g(pre + "conv1x1.bias"), R, TCN_HIDDEN, TCN_HIDDEN, sAct, sP, 3, s)
             if tn_ok:
                 # slab[k][c] = sum_r dpre1[r][k] * Xin[r][c] = dW1
-                H.call("nppc_gemm_tn_splitk_batched", h2b, TCN_HIDDEN, sAct, Xin, ldC, R * ldC, slab2, ldC,
-                       S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, s)
-                H.call("nppc_reduce_slabs", slab2, S2, TCN_HIDDEN * ldC, ldC, self.g(pre + "conv1x1.weight"), C, TCN_HIDDEN, 0,
-                       C, 0, 0, S2 * TCN_HIDDEN * ldC, sP, 3, s)
+                def c1_wgrad(h2b=h2b, Xin=Xin, dest=self.g(pre + "conv1x1.weight")):
+                    q = H.stream()
+                    H.call("nppc_gemm_tn_splitk_batched", h2b, TCN_HIDDEN, sAct, Xin, ldC, R * ldC, slab2, ldC,
+                           S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, q)
+                    H.call("nppc_reduce_slabs", slab2, S2, TCN_HIDDEN * ldC, ldC, dest, C, TCN_HIDDEN, 0, C, 0, 0,
+                           S2 * TCN_HIDDEN * ldC, sP, 3, q)
+                on_side(c1_wgrad)
             else:
                 H.call("nppc_transpose", prec, h2b, tA, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTA, 0, 3, s)
                 H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
@@ -488,6 +523,8 @@ class FSNEngine:
             H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
                    R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
             dXo, dXi = dXi, dXo
+        if tn_ok:
+            dXo = dXL[0]
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
         sv = d["tsse_saved"]
         dsg = ws("dsg", (B * (2 * F + F // 2),), torch.float32)      # dsg | da2 | da1 (csrc/spec.hip: nppc_tsse_bwd)
