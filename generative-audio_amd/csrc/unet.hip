@@ -270,15 +270,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ X, 
   const long p0 = (long)blockIdx.x * rows_per_block;
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
   if (r < rl)
-    for (long p = p0 + r; p < p1; p += rl) {
-      float xv[8];
-      load8<T>(X + p * ld + g8 * 8, xv);
+    for (long p = p0 + r; p < p1; p += 4 * rl) {          // four rows in flight per thread (halo rows are zero: no test)
+      float xv[4][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const double v = (double)xv[i];
-        s1[i] += v;
-        s2[i] += v * v;
-      }
+      for (int j = 0; j < 4; ++j)
+        if (p + j * rl < p1) load8<T>(X + (p + j * rl) * ld + g8 * 8, xv[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p + j * rl < p1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const double v = (double)xv[j][i];
+            s1[i] += v;
+            s2[i] += v * v;
+          }
+        }
     }
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
@@ -358,24 +364,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const long p0 = (long)blockIdx.x * rows_per_block;
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
   if (r < rl)
-    for (long p = p0 + r; p < p1; p += rl) {
-      if (!interior(p, P, H, W)) continue;
-      float av[8], bv[8], yv[8], xv[8];
-      load8<T>(dyA + p * ldA + g8 * 8, av);
-      if (dyB) {
-        load8<T>(dyB + p * ldB + g8 * 8, bv);
+    for (long p = p0 + r; p < p1; p += 2 * rl) {          // two rows (6-8 loads of 16 bytes) in flight per thread
+      float av[2][8], bv[2][8], yv[2][8], xv[2][8];
+      bool ok[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) av[i] += bv[i];
+      for (int j = 0; j < 2; ++j) {
+        const long q = p + j * rl;
+        ok[j] = q < p1 && interior(q, P, H, W);
+        if (ok[j]) {
+          load8<T>(dyA + q * ldA + g8 * 8, av[j]);
+          if (dyB) load8<T>(dyB + q * ldB + g8 * 8, bv[j]);
+          load8<T>(Y + q * ldy + g8 * 8, yv[j]);
+          load8<T>(X + q * ldx + g8 * 8, xv[j]);
+        }
       }
-      load8<T>(Y + p * ldy + g8 * 8, yv);
-      load8<T>(X + p * ldx + g8 * 8, xv);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float gq = av[i];
-        if (!(yv[i] > 0.f)) gq *= slope;
-        s1[i] += gq;
-        s2[i] += gq * ((xv[i] - mean[i]) * rstd[i]);
-      }
+      for (int j = 0; j < 2; ++j)
+        if (ok[j]) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float gq = dyB ? av[j][i] + bv[j][i] : av[j][i];
+            if (!(yv[j][i] > 0.f)) gq *= slope;
+            s1[i] += gq;
+            s2[i] += gq * ((xv[j][i] - mean[i]) * rstd[i]);
+          }
+        }
     }
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = s1[i]; red[1][threadIdx.x][i] = s2[i]; }
