@@ -923,7 +923,9 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   const int tc_ = tid % TPR;
   struct Saved { u32x4 g[4]; unsigned ct[4], cp[4], dh[4]; };     // packed bf16 pairs: 28 VGPRs
   auto ld_nt4 = [](const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); };
-  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t) {
+  // carry: sv still holds the (consumed) state of step t + 1, whose "previous cell" c_t is this step's cell state:
+  // moved in registers instead of being read from HBM a second time
+  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t, bool carry) {
     if (!prow_ok || t < 0) return;
     int tc = tc_;
     asm volatile("" : "+v"(tc));          // keep the per-chunk addresses out of the loop-invariant (spilled) set
@@ -932,7 +934,8 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     for (int j = 0; j < 4; ++j) {
       const int c = tc + TPR * j;
       sv.g[j] = ld_nt16(gs + e * 4 + 8 * c);
-      sv.ct[j] = ld_nt4(cs + e + 2 * c);
+      if (carry) sv.ct[j] = sv.cp[j];
+      else sv.ct[j] = ld_nt4(cs + e + 2 * c);
       if (t > 0) sv.cp[j] = ld_nt4(cs + e - (size_t)N * H + 2 * c);
       if (dh_ext) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
     }
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   };
 
   Saved sv2, sv1;
-  fetch(sv2, g2, c2, dh2, a.Tn - 1);
+  fetch(sv2, g2, c2, dh2, a.Tn - 1, false);
 #ifdef C2_STAMP
   st_last = __builtin_readcyclecounter();
 #endif
@@ -1102,7 +1105,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     // occupies a CU's memory queue for ~12k cycles -- per-CU miss parallelism, not chip-wide HBM contention: starting
     // the clusters an eighth of a step apart changed nothing.)
     // ---------------- LSTM layer 2 (exchange layer index 1)
-    fetch(sv1, g1, c1, nullptr, t);                    // layer-1 state of this step
+    fetch(sv1, g1, c1, nullptr, t, t < a.Tn - 1);      // layer-1 state of this step
     cell_bwd(sv2, dhrec2, true, dc2, t, dg2T);
     C2T(0)
     __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     C2T(2)
     layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
     // ---------------- LSTM layer 1 (exchange layer index 0)
-    fetch(sv2, g2, c2, dh2, t - 1);                    // layer-2 state of the next (earlier) step
+    fetch(sv2, g2, c2, dh2, t - 1, true);              // layer-2 state of the next (earlier) step
     cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
     C2T(9)
     __syncthreads();
