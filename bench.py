@@ -190,6 +190,11 @@ def main():
                      "all_lstm_kernels": kern},
     }
     log(f"timed region done: {1e3 * dt / a.steps:.1f} ms/step")
+    from nppc_audio import ops_lstm
+    nto = ops_lstm.coop_timeouts()
+    if nto:      # a bounded hand-off spin gave up: the step's results are wrong, so is any number measured on them
+        raise RuntimeError(f"{nto} cooperative LSTM hand-off time-outs during the run: measurement invalid")
+    out["lstm_handoff_timeouts"] = 0
     if world == 1 and not a.no_cpu_baseline:
         log("timing the CPU baseline (bounded sample)")
         out["cpu_baseline"] = cpu_baseline()

@@ -40,3 +40,42 @@ def test_gemm_nt_splitk_matches_matmul(prec):
     torch.cuda.synchronize()
     ref = A.float().cpu().double() @ B.float().cpu().double().t()
     assert (C.sum(0).cpu().double() - ref).abs().max().item() < (2e-3 if prec == 0 else 1e-4) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,cols,ld,batch", [(8192, 512, 512, 3), (8192, 257, 320, 3), (200000, 64, 64, 1),
+                                                (1000, 100, 100, 2), (77, 24, 24, 1)])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_colsum_variants_match_torch(rows, cols, ld, batch, prec):
+    """bias gradients: the 16-byte path (padded rows, few large workgroups for tall matrices) and the scalar fallback"""
+    from nppc_audio import _hip as H
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(rows + cols)
+    M = torch.zeros(batch, rows, ld, dtype=dt, device="cuda")
+    M[:, :, :cols] = torch.randn(batch, rows, cols, generator=g).to(dt).cuda()
+    out = torch.full((batch, cols + 3), 0.5, dtype=torch.float32, device="cuda")      # accumulates; neighbours untouched
+    H.call("nppc_colsum", prec, M, out, rows, cols, ld, rows * ld, cols + 3, batch, H.stream())
+    want = M[:, :, :cols].double().sum(dim=1).cpu() + 0.5
+    got = out.cpu().double()
+    assert float((got[:, :cols] - want).abs().max()) < 2e-4 * (rows ** 0.5) + 1e-3
+    assert float((got[:, cols:] - 0.5).abs().max()) == 0.0
+
+
+def test_pack_matrix_batched_equals_per_matrix_packs():
+    from nppc_audio import _hip as H
+    g = torch.Generator().manual_seed(1)
+    na, nb, N, K, Npad, ldd = 4, 3, 37, 50, 48, 64
+    lay, brs = 3000, 20000                                   # element strides of the (a, b) grid inside one flat buffer
+    flat = torch.randn(na * lay + nb * brs + N * K, generator=g).cuda()
+    for tr in (0, 1):
+        shape = (N, K) if not tr else (K, N)                 # transpose: src is [K][N], dst[n][k] = src[k][n]
+        dst = torch.full((na, nb, Npad, ldd), 7.0, dtype=torch.bfloat16, device="cuda")
+        H.call("nppc_pack_matrix_batched", 0, flat, dst, N, K, Npad, ldd, tr, na, nb, lay, brs, dst.stride(0), dst.stride(1),
+               H.stream())
+        for a in range(na):
+            for b in range(nb):
+                one = torch.full((Npad, ldd), 7.0, dtype=torch.bfloat16, device="cuda")
+                H.call("nppc_pack_matrix", 0, flat[a * lay + b * brs:], one, N, K, Npad, ldd, tr, H.stream())
+                assert torch.equal(dst[a, b], one), (tr, a, b)
+                src = flat[a * lay + b * brs: a * lay + b * brs + N * K].reshape(shape)
+                ref = (src if not tr else src.t()).to(torch.bfloat16)
+                assert torch.equal(one[:N, :K], ref) and float(one[N:].abs().max()) == 0.0
