@@ -72,6 +72,26 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def pmc_traffic(dom_name):
+    """HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) from the committed
+    rocprofv3 counter passes of this same command (profiles/r01_bench_c2_bf16_pmc_traffic.csv, tools/summarize_pmc.py):
+    counters cannot be collected from inside the timed process, so the figure is null when that file is absent or the
+    run is not the default C2 configuration it was measured on."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_bench_c2_bf16_pmc_traffic.csv")
+    key = {"lstm2_bwd_coop_ksplit": "lstm2_coop_bwd2_kernel", "lstm2_fwd_coop_g2[N=8224": "2, 5, 64, false",
+           "lstm2_fwd_coop_g2[N=4096": "2, 2, 64, true"}
+    pat = next((v for k, v in key.items() if dom_name.startswith(k)), None)
+    if pat is None or not os.path.exists(path) or "N=8224" not in dom_name and "N=4096" not in dom_name:
+        return None, "no committed PMC pass for this kernel / configuration"
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if pat in r["kernel"]:
+                mb = float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])
+                return mb * 1048576.0, "bytes per launch, profiles/r01_bench_c2_bf16_pmc_traffic.csv (separate --pmc passes)"
+    return None, "kernel not in the committed PMC summary"
+
+
 def cpu_baseline():
     """Reference-shaped CPU path (the oracle restatement, pinned to the reference by tests/golden) on a bounded
     sample: B=4 x 4 s, K=5, G_pc=2, one full train step (forward x [2 restorer, 3 STFT] + backward + Adam)."""
@@ -190,6 +210,9 @@ def main():
                      "all_lstm_kernels": kern},
     }
     log(f"timed region done: {1e3 * dt / a.steps:.1f} ms/step")
+    tr_bytes, tr_src = pmc_traffic(dom_name)
+    out["roofline"]["traffic"] = tr_bytes
+    out["roofline"]["traffic_note"] = tr_src
     from nppc_audio import ops_lstm
     nto = ops_lstm.coop_timeouts()
     if nto:      # a bounded hand-off spin gave up: the step's results are wrong, so is any number measured on them

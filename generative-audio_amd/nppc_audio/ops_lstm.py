@@ -1,5 +1,6 @@
 """Host side of the fused 2-layer LSTM kernels (csrc/lstm.hip)."""
 import ctypes
+import os
 
 import torch
 
@@ -80,7 +81,7 @@ def workspace(key, shape, dtype, device, zero=False):
 
 
 COOP_BWD_KSPLIT = True    # cooperative backward variant: True = K-split (bf16 partial-sum exchange), False = output-split
-WGRAD_SPLITS = 64    # K-slices of the weight-gradient GEMMs (engine._lstm_wgrad)
+WGRAD_SPLITS = int(os.environ.get("NPPC_WGRAD_SPLITS", "64"))    # K-slices of the weight-gradient GEMMs (engine._lstm_wgrad)
 ROW_PAD = 64 * WGRAD_SPLITS   # row granularity of their operands: 64-row stages x K-slices; buffers carry this much slack
 
 
