@@ -25,6 +25,7 @@ def rup(a, b):
 
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
+TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
 
 
 class FlatParams:
@@ -418,7 +419,7 @@ class FSNEngine:
         H.call("nppc_subband_stage_bwd", prec, dx, d["x_tm"], d["fb"], d["sbscale"], Dsb, dpre_fb, B, F, Tp, Tv, ldF, R * ldF,
                self.nb, self.G, self.KX, s)
         # ---- 5. fc_output_layer backward
-        S2 = 8 if R % (32 * 8) == 0 else 1
+        S2 = TCN_WGRAD_SPLITS if R % (64 * TCN_WGRAD_SPLITS) == 0 else (8 if R % (32 * 8) == 0 else 1)
         Fr = rup(F, 128)
         Cr = rup(ldC, 128)
         tA = ws("tA", (3, max(Cr, TCN_HIDDEN, Fr), R), zero=True)       # transposed dY operand
