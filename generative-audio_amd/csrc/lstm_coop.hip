@@ -45,6 +45,9 @@ struct CoopArgs {
   void* xch;          // [clusters][2 layers][2 parities][G][MC][HC]  exchange slices
   unsigned* flags;    // [clusters][2 layers][G] epochs, then 1 timeout word; zeroed before every launch
   long N; int Tn; int clusters;
+  // fused output head (inference): whp [16][H] row-major (rows >= O zero), hpart [G][Tn][N][O] fp32 partial sums of
+  // sum_u h2[t][n][u] * Wh[o][u] over the units of CU g; whp == nullptr: h2 is stored instead
+  const void* whp; float* hpart; int O;
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -168,7 +171,7 @@ template <typename T> __device__ __forceinline__ void store1_nt(T* p, float v) {
 #define FT(i)
 #endif
 
-template <typename T, int G, int MT, int KX, bool TRAIN>
+template <typename T, int G, int MT, int KX, bool TRAIN, bool HEAD = false>
 __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(CoopArgs a) {
 #ifdef CF_STAMP
   unsigned long long ft_last = __builtin_readcyclecounter(), ft_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -503,7 +506,29 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     if (more) publish(1, OH2, ep);
     FT(12)
 #ifndef CF_NO_SAVE
-    flush_state(h2o, c2o, sc2, OH2, t);                           // inference: h2 only (the head reads it)
+    if constexpr (HEAD) {
+      // Linear(H -> O) on the own h2_t slice, still in LDS as the MFMA A operand: wave w multiplies row tile w by the
+      // own units' head weights (6 k-steps, B fragments from L2) and leaves O partial sums per row; the 1.6 GB of h2
+      // stores, their re-read by a head kernel and that launch disappear (the partner's half is added by the finaliser)
+      if (wave < MT) {
+        int nn = lane & 15, qq = lane >> 4;
+        asm volatile("" : "+v"(nn), "+v"(qq));     // re-derive the addresses each step: hoisted, they were spilled
+        const T* ap = lds + (16 * wave + nn) * RS + OH2 + cu * HC + 8 * qq;
+        const T* bp = reinterpret_cast<const T*>(a.whp) + (size_t)nn * H + cu * HC + 8 * qq;
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HC / 32; ++kk) hacc = mma16(load_frag<T>(ap + 32 * kk), load_frag<T>(bp + 32 * kk), hacc);
+        if (nn < a.O) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const long r = row0 + 16 * wave + 4 * qq + j;
+            if (r < N) a.hpart[(((size_t)cu * a.Tn + t) * N + r) * a.O + nn] = hacc[j];
+          }
+        }
+      }
+    } else {
+      flush_state(h2o, c2o, sc2, OH2, t);                         // inference without a fused head: h2 only
+    }
 #endif
   }
 #ifdef CF_STAMP
@@ -1164,7 +1189,7 @@ __global__ void lstm_coop_pack_bwd2_kernel(const float* __restrict__ w_ih, const
   }
 }
 
-template <typename T, int G, int MT, bool TRAIN>
+template <typename T, int G, int MT, bool TRAIN, bool HEAD = false>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
   constexpr int RS = 2 * KX + 2 * H + 16 / (int)sizeof(T);
@@ -1174,7 +1199,7 @@ static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   if (smem > 160 * 1024) return NPPC_EUNSUPPORTED;
   const long need = (long)a.clusters * 2 * 2 * G * MC * (H / G) * sizeof(T);
   if ((long)xch_bytes < need) return NPPC_EBADARG;
-  auto k = lstm2_coop_fwd_kernel<T, G, MT, KX, TRAIN>;
+  auto k = lstm2_coop_fwd_kernel<T, G, MT, KX, TRAIN, HEAD>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
       hipSuccess)
     return NPPC_ELAUNCH;
@@ -1209,14 +1234,16 @@ int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, i
 }
 
 // flags: (clusters*2*G + 4) u32; xch: clusters*2*2*G*MC*(H/G) elements.  Same tensor contract as nppc_lstm2_fwd.
-int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
-                        const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
-                        void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, void* stream) {
+static int fwd_coop_impl(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
+                         const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                         void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
+                         float* hpart, int O, void* stream) {
   if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4)) return NPPC_EUNSUPPORTED;
-  if (!x || !wp1 || !wp2 || !h2 || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
+  if (!x || !wp1 || !wp2 || (!h2 && !whp) || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
   if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
+  if (whp && (train || G != 2 || !hpart || O < 1 || O > 16)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
-  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC)};
+  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC), whp, hpart, O};
   hipStream_t s = (hipStream_t)stream;
   if (G == 4) {
     if (mtile == 4)
@@ -1229,9 +1256,28 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
     if (mtile == 2) return launch_coop<bf16_t, 2, 2, true>(a, (size_t)xch_bytes, s);
     return NPPC_EUNSUPPORTED;
   }
+  if (whp) {
+    if (mtile == 2) return launch_coop<bf16_t, 2, 2, false, true>(a, (size_t)xch_bytes, s);
+    if (mtile == 5) return launch_coop<bf16_t, 2, 5, false, true>(a, (size_t)xch_bytes, s);
+    return NPPC_EUNSUPPORTED;
+  }
   if (mtile == 2) return launch_coop<bf16_t, 2, 2, false>(a, (size_t)xch_bytes, s);
   if (mtile == 5) return launch_coop<bf16_t, 2, 5, false>(a, (size_t)xch_bytes, s);
   return NPPC_EUNSUPPORTED;
+}
+
+int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
+                        const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                        void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, void* stream) {
+  return fwd_coop_impl(prec, train, G, mtile, x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, xch_bytes, flags, N, Tn, I,
+                       H, nullptr, nullptr, 0, stream);
+}
+
+int nppc_lstm2_fwd_coop_head(int prec, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
+                             const float* bias2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H,
+                             const void* whp, float* hpart, int O, void* stream) {
+  return fwd_coop_impl(prec, 0, 2, mtile, x, wp1, wp2, bias1, bias2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xch,
+                       xch_bytes, flags, N, Tn, I, H, whp, hpart, O, stream);
 }
 
 // cooperative backward (bf16, H = 384, I <= 64): packed weights of nppc_lstm2_coop_bwd_pack; xch holds

@@ -158,9 +158,49 @@ __global__ void head_scalar_kernel(const T* __restrict__ h2, const T* __restrict
   }
 }
 
+// out[bo][o][fo][t - la] = bias[o] + sum_g hpart[g][t][n][o]   (partial sums of the head fused into the cooperative LSTM
+// forward, one per CU of a pair).  32 frames x 32 sequences per workgroup through an LDS tile: reads run along (n, o),
+// writes along t.
+constexpr int HF_OMAX = 4;
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ hpart, int G, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long Nseq, int Tn, int la, int O, int Fo) {
+  __shared__ float tile[32][32 * HF_OMAX + 1];
+  const long n0 = (long)blockIdx.x * 32;
+  const int t0 = la + blockIdx.y * 32, To = Tn - la, w = 32 * O;
+  for (int e = threadIdx.x; e < 32 * w; e += 256) {
+    const int tt = e / w, c = e % w;                         // c = n_local * O + o
+    const long nn = n0 + c / O;
+    float v = 0.f;
+    if (t0 + tt < Tn && nn < Nseq)
+      for (int g = 0; g < G; ++g) v += hpart[(((size_t)g * Tn + t0 + tt) * Nseq + n0) * O + c];
+    tile[tt][c] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * w; e += 256) {
+    const int tt = e % 32, c = e / 32;
+    const long nn = n0 + c / O;
+    const int o = c % O;
+    if (t0 + tt < Tn && nn < Nseq) {
+      const long bo = nn / Fo, fo = nn % Fo;
+      out[((bo * O + o) * Fo + fo) * To + (t0 + tt - la)] = tile[tt][c] + bias[o];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
+                          void* stream) {
+  if (!hpart || !bias || !out || G < 1 || Nseq <= 0 || Tn <= la || O < 1 || Nseq % Fo) return NPPC_EBADARG;
+  if (O > HF_OMAX) return NPPC_EUNSUPPORTED;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(ceil_div(Nseq, 32L), ceil_div(Tn - la, 32)), dim3(256), 0, (hipStream_t)stream,
+                     hpart, G, bias, out, Nseq, Tn, la, O, Fo);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
 
 int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* mult,
                       float* scale, int B, int F, int Tp, int Tv, int nfeat, void* stream) {

@@ -26,6 +26,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
+FUSED_HEAD = os.environ.get("NPPC_FUSED_HEAD", "1") != "0"            # A/B switch: inference head inside the LSTM kernel
 
 
 class FlatParams:
@@ -290,12 +291,18 @@ class FSNEngine:
         H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
                self.nb, self.G, self.KX, int(train), s)
         # 7: two-layer LSTM over T' steps for the B*F' sequences
-        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile)      # mtile None: cooperative kernel when the shape allows
+        # mtile None: cooperative kernel when the shape allows; inference hands it the output head to fuse (bf16 pair kernel)
+        head = (self.Whp, self.O) if (FUSED_HEAD and not train and prec == H.PREC_BF16 and self.Opad == 16) else None
+        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
         out = torch.empty(B, self.O, d["Fo"], T, dtype=torch.float32, device=self.dev)
-        H.call("nppc_sb_head", prec, lo["h2"], self.Whp, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
-               self.la, self.Hd, self.O, d["Fo"], s)
+        if "head_partial" in lo:
+            H.call("nppc_sb_head_finalize", lo["head_partial"], 2, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
+                   self.la, self.O, d["Fo"], s)
+        else:
+            H.call("nppc_sb_head", prec, lo["h2"], self.Whp, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
+                   self.la, self.Hd, self.O, d["Fo"], s)
         self.last = d
         return out
 

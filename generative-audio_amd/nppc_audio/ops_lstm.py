@@ -95,10 +95,16 @@ def rows_view(flat, Tn, N):
     return flat[:Tn * N].view(Tn, N, flat.shape[1])
 
 
-def lstm2_forward(x_tm, packed, train, mtile=None):
+FUSED_HEAD_MAX_O = 4     # nppc_sb_head_finalize's tile; the restorer's head has 2 outputs
+
+
+def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
     """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1, g1, g2, c1, c2]) time-major.
     In train mode h1/h2 are prefixes of zero-padded row buffers (`h1_rows`, `h2_rows`: [Rpad][H]) that the
-    weight-gradient GEMMs read directly."""
+    weight-gradient GEMMs read directly.
+    head = (whp [16][H] packed head weights, O): inference only -- when the cooperative pair kernel runs, the output
+    head is fused into it and the result is dict(head_partial [2][Tn][N][O] fp32) instead of h2 (the caller finishes
+    with nppc_sb_head_finalize); any other plan ignores `head` and returns h2."""
     Tn, N, kx = x_tm.shape
     assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
@@ -115,8 +121,6 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
-    else:
-        out["h2"] = workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)
     if (COOP and mtile is None) or isinstance(mtile, tuple):
         G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if isinstance(mtile, tuple):               # (G, mtile) forced by a test / benchmark
@@ -130,6 +134,16 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
             G, cmt, ncl = G.value, cmt.value, ncl.value
             xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 16 * cmt * Hd,), dt, dev)
             flags = workspace(tag + ("coop_flags",), (ncl * 2 * G + 4,), torch.int32, dev, zero=True)
+            if head is not None and not train and G == 2 and head[1] <= FUSED_HEAD_MAX_O:
+                whp, O = head
+                out["head_partial"] = workspace(tag + ("hpart", O), (2, Tn, N, O), torch.float32, dev)
+                _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
+                    "nppc_lstm2_fwd_coop_head", packed.prec, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
+                    xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, whp, out["head_partial"], O,
+                    H.stream()))
+                return out
+            if not train:
+                out["h2"] = workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)
             _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
                 "nppc_lstm2_fwd_coop", packed.prec, int(train), G, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
                 packed.bias2, out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), xch,
@@ -137,6 +151,8 @@ def lstm2_forward(x_tm, packed, train, mtile=None):
             return out
     if mtile is None:
         mtile = pick_mtile(N, packed.prec, train)
+    if not train:
+        out["h2"] = workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)
     _timed(("lstm2_fwd", int(train), N, Tn, mtile), lambda: H.call(
         "nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
         out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,

@@ -202,3 +202,39 @@ def test_cooperative_backward_matches_single_workgroup_kernel(N, Tn):
         x, y = x.float(), y.float()
         d = (x - y).abs().max().item() / (y.abs().max().item() + 1e-30)
         assert d < 2e-2, (name, d)
+
+
+@pytest.mark.parametrize("N,Tn,force,O,Fo,la", [(96, 9, (2, 2), 2, 48, 2), (200, 7, (2, 5), 2, 100, 0), (161, 5, (2, 5), 4, 161, 1)])
+def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
+    """inference: Linear(H -> O) fused into the CU-pair kernel (per-CU partial sums + nppc_sb_head_finalize) against the
+    same kernel storing h2 followed by nppc_sb_head (ragged last row tile, look-ahead crop, several samples)"""
+    from nppc_audio import _hip as H
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import PackedLSTM, lstm2_forward
+    I, Hd = 34, 384
+    P = _weights(I, Hd, 3)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in (
+        "weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
+    g = torch.Generator().manual_seed(N + O)
+    xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
+    xt[:, :, :I] = torch.randn(Tn, N, I, generator=g).to(dev)
+    wh = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev)
+    wh[:O] = (torch.randn(O, Hd, generator=g) * 0.1).to(dev)
+    bias = torch.randn(O, generator=g).to(dev)
+    Bq = N // Fo
+    s = H.stream()
+    plain = lstm2_forward(xt, pk, False, force)
+    want = torch.empty(Bq, O, Fo, Tn - la, dtype=torch.float32, device=dev)
+    H.call("nppc_sb_head", 0, plain["h2"], wh, bias, want, N, Tn, la, Hd, O, Fo, s)
+    fused = lstm2_forward(xt, pk, False, force, head=(wh, O))
+    assert "head_partial" in fused and "h2" not in fused and ops_lstm.coop_timeouts() == 0
+    got = torch.full_like(want, float("nan"))
+    H.call("nppc_sb_head_finalize", fused["head_partial"], 2, bias, got, N, Tn, la, O, Fo, s)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))      # same bf16 operands, fp32 sums
+    # a plan without the pair kernel ignores the request and returns h2
+    single = lstm2_forward(xt, pk, False, 1, head=(wh, O))
+    assert "h2" in single and "head_partial" not in single
