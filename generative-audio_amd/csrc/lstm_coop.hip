@@ -526,9 +526,8 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           }
         }
       }
-    } else {
-      flush_state(h2o, c2o, sc2, OH2, t);                         // inference without a fused head: h2 only
     }
+    if constexpr (TRAIN || !HEAD) flush_state(h2o, c2o, sc2, OH2, t);   // training keeps h2 / c2; inference only without a fused head
 #endif
   }
 #ifdef CF_STAMP
@@ -1239,9 +1238,9 @@ static int fwd_coop_impl(int prec, int train, int G, int mtile, const void* x, c
                          void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
                          float* hpart, int O, void* stream) {
   if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4)) return NPPC_EUNSUPPORTED;
-  if (!x || !wp1 || !wp2 || (!h2 && !whp) || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
+  if (!x || !wp1 || !wp2 || (!h2 && (!whp || train)) || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
   if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
-  if (whp && (train || G != 2 || !hpart || O < 1 || O > 16)) return NPPC_EBADARG;
+  if (whp && (G != 2 || !hpart || O < 1 || O > 16)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
   CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC), whp, hpart, O};
   hipStream_t s = (hipStream_t)stream;
@@ -1253,7 +1252,8 @@ static int fwd_coop_impl(int prec, int train, int G, int mtile, const void* x, c
     return NPPC_EUNSUPPORTED;
   }
   if (train) {
-    if (mtile == 2) return launch_coop<bf16_t, 2, 2, true>(a, (size_t)xch_bytes, s);
+    if (mtile == 2) return whp ? launch_coop<bf16_t, 2, 2, true, true>(a, (size_t)xch_bytes, s)
+                               : launch_coop<bf16_t, 2, 2, true>(a, (size_t)xch_bytes, s);
     return NPPC_EUNSUPPORTED;
   }
   if (whp) {
@@ -1273,11 +1273,13 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
                        H, nullptr, nullptr, 0, stream);
 }
 
-int nppc_lstm2_fwd_coop_head(int prec, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                             const float* bias2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H,
-                             const void* whp, float* hpart, int O, void* stream) {
-  return fwd_coop_impl(prec, 0, 2, mtile, x, wp1, wp2, bias1, bias2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xch,
-                       xch_bytes, flags, N, Tn, I, H, whp, hpart, O, stream);
+int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2,
+                             const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                             void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
+                             float* hpart, int O, void* stream) {
+  if (!whp) return NPPC_EBADARG;
+  return fwd_coop_impl(prec, train, 2, mtile, x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, xch_bytes, flags, N, Tn, I,
+                       H, whp, hpart, O, stream);
 }
 
 // cooperative backward (bf16, H = 384, I <= 64): packed weights of nppc_lstm2_coop_bwd_pack; xch holds

@@ -159,14 +159,15 @@ __global__ void head_scalar_kernel(const T* __restrict__ h2, const T* __restrict
 }
 
 // out[bo][o][fo][t - la] = bias[o] + sum_g hpart[g][t][n][o]   (partial sums of the head fused into the cooperative LSTM
-// forward, one per CU of a pair).  32 frames x 32 sequences per workgroup through an LDS tile: reads run along (n, o),
-// writes along t.
-constexpr int HF_OMAX = 4;
+// forward, one per CU of a pair).  32 frames x ns sequences (ns * O <= 128 columns) per workgroup through an LDS tile:
+// reads run along (n, o), writes along t.
+constexpr int HF_COLS = 128;
 __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ hpart, int G, const float* __restrict__ bias,
-                                                            float* __restrict__ out, long Nseq, int Tn, int la, int O, int Fo) {
-  __shared__ float tile[32][32 * HF_OMAX + 1];
-  const long n0 = (long)blockIdx.x * 32;
-  const int t0 = la + blockIdx.y * 32, To = Tn - la, w = 32 * O;
+                                                            float* __restrict__ out, long Nseq, int Tn, int la, int O, int Fo,
+                                                            int ns) {
+  __shared__ float tile[32][HF_COLS + 1];
+  const long n0 = (long)blockIdx.x * ns;
+  const int t0 = la + blockIdx.y * 32, To = Tn - la, w = ns * O;
   for (int e = threadIdx.x; e < 32 * w; e += 256) {
     const int tt = e / w, c = e % w;                         // c = n_local * O + o
     const long nn = n0 + c / O;
@@ -194,9 +195,10 @@ extern "C" {
 int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
                           void* stream) {
   if (!hpart || !bias || !out || G < 1 || Nseq <= 0 || Tn <= la || O < 1 || Nseq % Fo) return NPPC_EBADARG;
-  if (O > HF_OMAX) return NPPC_EUNSUPPORTED;
-  hipLaunchKernelGGL(head_finalize_kernel, dim3(ceil_div(Nseq, 32L), ceil_div(Tn - la, 32)), dim3(256), 0, (hipStream_t)stream,
-                     hpart, G, bias, out, Nseq, Tn, la, O, Fo);
+  if (O > 16) return NPPC_EUNSUPPORTED;
+  const int ns = HF_COLS / O;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(ceil_div(Nseq, (long)ns), ceil_div(Tn - la, 32)), dim3(256), 0,
+                     (hipStream_t)stream, hpart, G, bias, out, Nseq, Tn, la, O, Fo, ns);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

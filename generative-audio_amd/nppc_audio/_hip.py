@@ -71,7 +71,7 @@ SIGS = {
     "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "nppc_lstm2_coop_plan": [I, I, L, I, I, PI, PI, PI],
     "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P],
-    "nppc_lstm2_fwd_coop_head": [I, I, P, P, P, P, P, P, L, P, L, I, I, I, P, P, I, P],
+    "nppc_lstm2_fwd_coop_head": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P, P, I, P],
     "nppc_sb_head_finalize": [P, I, P, P, L, I, I, I, I, P],
     "nppc_lstm2_coop_bwd_packed_elems": [PL],
     "nppc_lstm2_coop_bwd_pack": [P, P, P, P, I, P, P, P],

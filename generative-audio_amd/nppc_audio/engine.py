@@ -26,7 +26,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
-FUSED_HEAD = os.environ.get("NPPC_FUSED_HEAD", "1") != "0"            # A/B switch: inference head inside the LSTM kernel
+FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "2"))                 # 0: head kernel, 1: fused in inference, 2: also in training
 
 
 class FlatParams:
@@ -291,8 +291,8 @@ class FSNEngine:
         H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
                self.nb, self.G, self.KX, int(train), s)
         # 7: two-layer LSTM over T' steps for the B*F' sequences
-        # mtile None: cooperative kernel when the shape allows; inference hands it the output head to fuse (bf16 pair kernel)
-        head = (self.Whp, self.O) if (FUSED_HEAD and not train and prec == H.PREC_BF16 and self.Opad == 16) else None
+        # mtile None: cooperative kernel when the shape allows; it also takes the output head to fuse (bf16 pair kernel)
+        head = (self.Whp, self.O) if (FUSED_HEAD > int(train) and prec == H.PREC_BF16 and self.Opad == 16) else None
         lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop

@@ -95,16 +95,16 @@ def rows_view(flat, Tn, N):
     return flat[:Tn * N].view(Tn, N, flat.shape[1])
 
 
-FUSED_HEAD_MAX_O = 4     # nppc_sb_head_finalize's tile; the restorer's head has 2 outputs
+FUSED_HEAD_MAX_O = 16    # one MFMA column tile
 
 
 def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
     """x_tm [Tn][N][kx] (time-major, zero padded to kx) -> dict(h2[, h1, g1, g2, c1, c2]) time-major.
     In train mode h1/h2 are prefixes of zero-padded row buffers (`h1_rows`, `h2_rows`: [Rpad][H]) that the
     weight-gradient GEMMs read directly.
-    head = (whp [16][H] packed head weights, O): inference only -- when the cooperative pair kernel runs, the output
-    head is fused into it and the result is dict(head_partial [2][Tn][N][O] fp32) instead of h2 (the caller finishes
-    with nppc_sb_head_finalize); any other plan ignores `head` and returns h2."""
+    head = (whp [16][H] packed head weights, O): when the cooperative pair kernel runs, the output head is fused into it
+    and the result carries head_partial [2][Tn][N][O] fp32 (the caller finishes with nppc_sb_head_finalize) -- in
+    inference INSTEAD of h2, in training beside the saved state; any other plan ignores `head`."""
     Tn, N, kx = x_tm.shape
     assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
@@ -134,11 +134,12 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
             G, cmt, ncl = G.value, cmt.value, ncl.value
             xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 16 * cmt * Hd,), dt, dev)
             flags = workspace(tag + ("coop_flags",), (ncl * 2 * G + 4,), torch.int32, dev, zero=True)
-            if head is not None and not train and G == 2 and head[1] <= FUSED_HEAD_MAX_O:
+            if head is not None and G == 2 and head[1] <= FUSED_HEAD_MAX_O and (not train or cmt == 2):
                 whp, O = head
                 out["head_partial"] = workspace(tag + ("hpart", O), (2, Tn, N, O), torch.float32, dev)
                 _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
-                    "nppc_lstm2_fwd_coop_head", packed.prec, cmt, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
+                    "nppc_lstm2_fwd_coop_head", packed.prec, int(train), cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
+                    packed.bias2, out.get("h2"), out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"),
                     xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, whp, out["head_partial"], O,
                     H.stream()))
                 return out

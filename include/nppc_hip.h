@@ -133,12 +133,14 @@ int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, i
 int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
                         const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
                         void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, void* stream);
-/* inference with the output head fused (SequenceModel.forward's fc_output_layer, sequence_model.py:119-123): instead of
- * h2 the CU pair leaves hpart [2][Tn][N][O] fp32 = per-CU partial sums of h2[t][n][:] . whp[o][:] (whp [16][H], rows >= O
- * zero); nppc_sb_head_finalize adds them, the bias, and writes out[bo][o][fo][t - la] like nppc_sb_head (O <= 4). */
-int nppc_lstm2_fwd_coop_head(int prec, int mtile, const void* x, const void* wp1, const void* wp2, const float* bias1,
-                             const float* bias2, void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H,
-                             const void* whp, float* hpart, int O, void* stream);
+/* the same with the output head fused (SequenceModel.forward's fc_output_layer, sequence_model.py:119-123): the CU pair
+ * also leaves hpart [2][Tn][N][O] fp32 = per-CU partial sums of h2[t][n][:] . whp[o][:] (whp [16][H], rows >= O zero);
+ * nppc_sb_head_finalize adds them and the bias and writes out[bo][o][fo][t - la] like nppc_sb_head (O <= 16).
+ * Inference (train = 0): h2 is not stored at all (h2 .. c2 may be null); training keeps the saved state. */
+int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2,
+                             const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
+                             void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
+                             float* hpart, int O, void* stream);
 int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
                           void* stream);
 /* cooperative backward (bf16, H = 384): CU pairs share 32 sequences, each owns half the hidden units / output columns */

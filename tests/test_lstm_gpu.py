@@ -238,3 +238,20 @@ def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
     # a plan without the pair kernel ignores the request and returns h2
     single = lstm2_forward(xt, pk, False, 1, head=(wh, O))
     assert "h2" in single and "head_partial" not in single
+    if force == (2, 2):
+        # training variant: saved state AND the fused head (K = 5 directions -> O = 10)
+        O2 = 10
+        wh2 = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev)
+        wh2[:O2] = (torch.randn(O2, Hd, generator=g) * 0.1).to(dev)
+        b2 = torch.randn(O2, generator=g).to(dev)
+        ref_state = {k: v.clone() for k, v in lstm2_forward(xt, pk, True, force).items()}
+        want2 = torch.empty(Bq, O2, Fo, Tn - la, dtype=torch.float32, device=dev)
+        H.call("nppc_sb_head", 0, ref_state["h2"], wh2, b2, want2, N, Tn, la, Hd, O2, Fo, s)
+        tr = lstm2_forward(xt, pk, True, force, head=(wh2, O2))
+        got2 = torch.full_like(want2, float("nan"))
+        H.call("nppc_sb_head_finalize", tr["head_partial"], 2, b2, got2, N, Tn, la, O2, Fo, s)
+        torch.cuda.synchronize()
+        assert ops_lstm.coop_timeouts() == 0
+        assert float((got2 - want2).abs().max()) < 2e-5 * max(1.0, float(want2.abs().max()))
+        for k in ("h1", "h2", "c1", "c2", "g1", "g2"):
+            assert torch.equal(tr[k], ref_state[k]), k
