@@ -832,6 +832,9 @@ struct CoopBwd2Args {
   void* xch;                          // [clusters][2 layers][2 parities][2 CUs][32][384] bf16 partial sums
   unsigned* flags;                    // [clusters][2 layers][2] epochs + timeout word
   long N; int Tn; int clusters;
+  // fused head backward: dyt [Tn][N][16] bf16 (dY rows, zero beyond O and before the look-ahead), whT [H][32] bf16
+  // ([u][o]); the kernel forms d h2 += dY . Wh itself and dh2 is not read
+  const void* dyt; const void* whT;
 };
 
 constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over the own gate columns
@@ -888,6 +891,7 @@ __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
 #define C2T(i)
 #endif
 
+template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
   typedef bf16_t T;
   constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
@@ -900,6 +904,8 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   float* dhrec2 = dh1buf + MC * HC;                                                   // [32][HC]    d h2 recurrent
   float* dxbuf = dhrec2 + MC * HC;                                                    // [32][32]    own d x partial
   T* stage = reinterpret_cast<T*>(dxbuf + MC * 32);                                   // [32][384]   partials for the partner
+  T* whs = stage + MC * C2_XW;                                                        // HEAD: [HC][16] own units' head weights
+  T* dys = whs + HC * 16;                                                             // HEAD: [32][16]  dY rows of one step
 
 #ifdef C2_STAMP
   C2_STAMP_INIT
@@ -914,6 +920,10 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   const long N = a.N;
   for (int i = tid; i < 2 * MC * HC + MC * 32; i += NT) dh1buf[i] = 0.f;
   for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
+  if constexpr (HEAD) {
+    const T* whT = reinterpret_cast<const T*>(a.whT);
+    for (int i = tid; i < HC * 16; i += NT) whs[i] = whT[(size_t)(cu * HC + i / 16) * 32 + (i % 16)];
+  }
 
   const int prow = tid / TPR;
   const bool prow_ok = row0 + prow < N;
@@ -1113,8 +1123,46 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     if (l2) { C2T(8) }
   };
 
+  // HEAD: the head's contribution to d h2_tau, dY_tau . Wh restricted to the own units, is formed here: the 32 dY rows of a
+  // step (1 KB) arrive by ONE LDS-DMA instruction of wave 0, every wave turns them into its 16-unit column tile with two
+  // MFMAs and adds the tile to dhrec2 -- no dh2 tensor is written by a head kernel or fetched with the saved state
+  const __amdgpu_buffer_rsrc_t dyr = make_rsrc(a.dyt, HEAD ? (unsigned)((size_t)a.Tn * N * 16 * sizeof(T)) : 0u);
+  auto dy_dma = [&](int tau) {
+    if constexpr (HEAD) {
+      if (wave == 0 && tau >= 0) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void*)dys, 16, lane * 16,
+                                                 (int)((((size_t)tau * N + row0) * 16) * sizeof(T)), 0, 0);
+      }
+    }
+  };
+  auto head_add = [&]() {
+    if constexpr (HEAD) {
+      int nn = lane & 15, qq = lane >> 4;
+      asm volatile("" : "+v"(nn), "+v"(qq));
+      bf16x8 bfr = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (qq < 2) bfr = load_frag<T>(whs + (16 * wave + nn) * 16 + 8 * qq);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        bf16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qq < 2) af = load_frag<T>(dys + (16 * mt + nn) * 16 + 8 * qq);
+        const f32x4 hv = mma16(af, bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dhrec2[(16 * mt + 4 * qq + j) * HC + 16 * wave + nn] += hv[j];
+      }
+    }
+  };
+  const T* dh2_src = HEAD ? nullptr : dh2;
+
   Saved sv2, sv1;
-  fetch(sv2, g2, c2, dh2, a.Tn - 1, false);
+  fetch(sv2, g2, c2, dh2_src, a.Tn - 1, false);
+  if constexpr (HEAD) {
+    dy_dma(a.Tn - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    head_add();
+    __syncthreads();
+  }
 #ifdef C2_STAMP
   st_last = __builtin_readcyclecounter();
 #endif
@@ -1130,14 +1178,16 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     // the clusters an eighth of a step apart changed nothing.)
     // ---------------- LSTM layer 2 (exchange layer index 1)
     fetch(sv1, g1, c1, nullptr, t, t < a.Tn - 1);      // layer-1 state of this step
-    cell_bwd(sv2, dhrec2, true, dc2, t, dg2T);
+    dy_dma(t - 1);                                     // HEAD: dY rows of the next (earlier) step
+    cell_bwd(sv2, dhrec2, !HEAD, dc2, t, dg2T);
     C2T(0)
     __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
     C2T(1)
     C2T(2)
     layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
+    if (t > 0) head_add();                             // HEAD: + dY_{t-1} . Wh (read by the next step's cell phase, barriers between)
     // ---------------- LSTM layer 1 (exchange layer index 0)
-    fetch(sv2, g2, c2, dh2, t - 1, true);              // layer-2 state of the next (earlier) step
+    fetch(sv2, g2, c2, dh2_src, t - 1, true);          // layer-2 state of the next (earlier) step
     cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
     C2T(9)
     __syncthreads();
@@ -1337,26 +1387,45 @@ int nppc_lstm2_coop_bwd2_pack(const float* w_ih0, const float* w_hh0, const floa
   return NPPC_OK;
 }
 
-int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
-                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
-                         int Tn, int n_cu, void* stream) {
-  if (!g1 || !g2 || !c1 || !c2 || !dh2 || !wb1 || !wb2 || !dx || !dg1 || !dg2 || !xch || !flags || N <= 0 || Tn <= 0)
+static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* dyt,
+                          const void* whT, const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch,
+                          long xch_bytes, unsigned* flags, long N, int Tn, int n_cu, void* stream) {
+  if (!g1 || !g2 || !c1 || !c2 || (!dh2 && !(dyt && whT)) || !wb1 || !wb2 || !dx || !dg1 || !dg2 || !xch || !flags || N <= 0 ||
+      Tn <= 0)
     return NPPC_EBADARG;
   const int clusters = (int)((N + CB_MC - 1) / CB_MC);
   if (clusters * CB_G > n_cu) return NPPC_EUNSUPPORTED;      // every workgroup of a cluster must be resident
   if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * C2_XW * 2) return NPPC_EBADARG;
-  CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters};
+  CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dyt, whT};
   hipStream_t s = (hipStream_t)stream;
   constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
-                          (size_t)CB_MC * C2_XW * 2;
+                          (size_t)CB_MC * C2_XW * 2 + (size_t)(CB_HC + CB_MC) * 16 * 2;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)smem) != hipSuccess)
-    return NPPC_ELAUNCH;
+  const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)
+                      : reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<false>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return NPPC_ELAUNCH;
   if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
-  hipLaunchKernelGGL(lstm2_coop_bwd2_kernel, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
+  if (dyt)
+    hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<true>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
+  else
+    hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<false>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
+}
+
+int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
+                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
+                         int Tn, int n_cu, void* stream) {
+  if (!dh2) return NPPC_EBADARG;
+  return bwd_coop2_impl(g1, g2, c1, c2, dh2, nullptr, nullptr, wb1, wb2, dx, dg1, dg2, xch, xch_bytes, flags, N, Tn, n_cu,
+                        stream);
+}
+
+int nppc_lstm2_bwd_coop2_head(const void* g1, const void* g2, const void* c1, const void* c2, const void* dyt, const void* whT,
+                              const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes,
+                              unsigned* flags, long N, int Tn, int n_cu, void* stream) {
+  if (!dyt || !whT) return NPPC_EBADARG;
+  return bwd_coop2_impl(g1, g2, c1, c2, nullptr, dyt, whT, wb1, wb2, dx, dg1, dg2, xch, xch_bytes, flags, N, Tn, n_cu, stream);
 }
 
 }  // extern "C"

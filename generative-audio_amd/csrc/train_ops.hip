@@ -196,6 +196,30 @@ static void launch_head_bwd_w(dim3 grid, int bw, hipStream_t s, const float* dou
   else hipLaunchKernelGGL((head_bwd_w_kernel<T, 32>), grid, dim3(bw), 0, s, dout, h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
 }
 
+// dyt[t][n][0..15] (bf16) = dout[bo][o][fo][t - la] for o < O, t >= la, else 0: the dY rows in the order the fused head
+// backward of lstm2_coop_bwd2_kernel<true> takes them (32 bytes per (t, n)); threads run along t, the contiguous axis of dout
+__global__ __launch_bounds__(256) void head_dy_gather_kernel(const float* __restrict__ dout, bf16_t* __restrict__ dyt, long Nseq,
+                                                             int Tn, int la, int O, int Fo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nseq * Tn) return;
+  const long nn = i / Tn;
+  const int t = (int)(i % Tn), To = Tn - la;
+  const long bo = nn / Fo, fo = nn % Fo;
+  unsigned w[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    float v0 = 0.f, v1 = 0.f;
+    if (t >= la) {
+      if (2 * p < O) v0 = dout[((bo * O + 2 * p) * Fo + fo) * To + (t - la)];
+      if (2 * p + 1 < O) v1 = dout[((bo * O + 2 * p + 1) * Fo + fo) * To + (t - la)];
+    }
+    w[p] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+  }
+  uint4* dst = reinterpret_cast<uint4*>(dyt + ((size_t)t * Nseq + nn) * 16);
+  dst[0] = uint4{w[0], w[1], w[2], w[3]};
+  dst[1] = uint4{w[4], w[5], w[6], w[7]};
+}
+
 // ---------------------------------------------------------------- sub-band staging backward
 // D[bo] = sum_{t, fo, j < nfeat} dx[t][n][j] * x[t][n][j]      (x = normalised LSTM input as staged)
 template <typename T>
@@ -379,6 +403,27 @@ int nppc_sb_head_bwd(int prec, const float* dout, const void* whT, const void* h
                        (float*)dh2, Nseq, Tn, la, Hd, O, Fo);
     launch_head_bwd_w<float>(gw, bw, s, dout, (const float*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
   }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_head_dy_gather(const float* dout, void* dyt, long Nseq, int Tn, int la, int O, int Fo, void* stream) {
+  if (!dout || !dyt || Nseq <= 0 || Tn <= la || O < 1 || O > 16 || Nseq % Fo) return NPPC_EBADARG;
+  hipLaunchKernelGGL(head_dy_gather_kernel, dim3(ceil_div(Nseq * Tn, 256L)), dim3(256), 0, (hipStream_t)stream, dout,
+                     (bf16_t*)dyt, Nseq, Tn, la, O, Fo);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_sb_head_bwd_w(int prec, const float* dout, const void* h2, float* dWh, float* dbh, long Nseq, int Tn, int la, int Hd,
+                       int O, int Fo, void* stream) {
+  if (!dout || !h2 || !dWh || !dbh || O > 32 || O < 1 || Nseq % Fo) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = ceil_div(Nseq, HB_ROWS);
+  dim3 gw(chunks < 4 ? chunks : 4, Tn - la);
+  const int bw = round_up(Hd, 64);
+  if (prec == NPPC_PREC_BF16) launch_head_bwd_w<bf16_t>(gw, bw, s, dout, (const bf16_t*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
+  else launch_head_bwd_w<float>(gw, bw, s, dout, (const float*)h2, dWh, dbh, Nseq, Tn, la, Hd, O, Fo);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, lstm2_backward, lstm2_forward, padded_rows,
+from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, bwd_head_fusable, lstm2_backward, lstm2_forward,
+                       padded_rows,
                        rows_view, workspace)
 
 TCN_HIDDEN = 512
@@ -26,7 +27,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
-FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "2"))                 # 0: head kernel, 1: fused in inference, 2: also in training
+FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "3"))    # 0: head kernels; 1: fused in the inference forward; 2: + training forward; 3: + backward
 
 
 class FlatParams:
@@ -404,11 +405,19 @@ class FSNEngine:
         lo = d["lstm"]
         # ---- 1. head: dh2 = dY Wh, dWh, dbh
         ws = lambda name, shape, dtype=dt, zero=False: workspace(("eng", id(self), name), shape, dtype, dev, zero)
-        dh2 = ws("dh2", (Tv, Nseq, Hd))
-        H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
-               self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
-        # ---- 2. LSTM recurrence backward
-        dx, dg1, dg2 = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
+        if FUSED_HEAD >= 3 and prec == H.PREC_BF16 and O <= 16 and bwd_head_fusable(Nseq, self.lstm_bwd):
+            # the K-split cooperative kernel forms d h2 = dY . Wh itself from the gathered dY rows: no dh2 tensor
+            dyt = ws("dyt", (Tv, Nseq, 16))
+            H.call("nppc_head_dy_gather", dout, dyt, Nseq, Tv, self.la, O, Fo, s)
+            H.call("nppc_sb_head_bwd_w", prec, dout, lo["h2"], self.g("sb_model.fc_output_layer.weight"),
+                   self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
+            dx, dg1, dg2 = lstm2_backward(lo, None, self.lstm_bwd, self.KX, head=(dyt, self.WhT))
+        else:
+            dh2 = ws("dh2", (Tv, Nseq, Hd))
+            H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
+                   self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
+            # ---- 2. LSTM recurrence backward
+            dx, dg1, dg2 = lstm2_backward(lo, dh2, self.lstm_bwd, self.KX)
         # ---- 3. LSTM weight gradients: dW[k][c] = sum_rows dgates[row][k] * input[row][c], rows = (t, sequence).
         # Row-major operands straight from the recurrent kernels; h_{t-1} is the same buffer one time block (Nseq rows)
         # earlier; the staged input carries a ones column (index I), so its product column is the bias gradient.

@@ -192,11 +192,18 @@ class PackedLSTMBwd:
         return self
 
 
-def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
+def bwd_head_fusable(N, packed_bwd, coop=None):
+    """True when lstm2_backward will run the K-split cooperative kernel, which can take the head backward (dyt, whT)"""
+    return bool((COOP if coop is None else coop) and packed_bwd.coop and ((N + 31) // 32) * 2 <= _n_cu() and COOP_BWD_KSPLIT)
+
+
+def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None, head=None):
     """saved = lstm2_forward(train=True) dict; dh2 [Tn][N][H] -> (dx [Tn][N][kx], dg1_rows, dg2_rows): the gate gradients
-    as zero-padded row buffers [Rpad][4H] (row t*N + n, column unit*4 + gate in (i,g,f,o) order)."""
+    as zero-padded row buffers [Rpad][4H] (row t*N + n, column unit*4 + gate in (i,g,f,o) order).
+    head = (dyt [Tn][N][16] bf16, whT [H][32] bf16) with dh2 None: the K-split cooperative kernel forms
+    d h2 = dY . Wh itself (only valid when bwd_head_fusable(N, packed_bwd))."""
     Tn, N, Hd = saved["h2"].shape
-    dt, dev = dh2.dtype, dh2.device
+    dt, dev = saved["h2"].dtype, saved["h2"].device
     tag = ("lstm_bwd", id(packed_bwd))
     dx = workspace(tag + ("dx",), (Tn, N, kx), dt, dev)
     Rp = padded_rows(Tn * N, N)
@@ -207,10 +214,17 @@ def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None):
         ncl = (N + 31) // 32
         xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 384,), dt, dev)
         flags = workspace(tag + ("coop_flags",), (ncl * 4 + 4,), torch.int32, dev, zero=True)
+        if head is not None:
+            dyt, whT = head
+            _timed(("lstm2_bwd_coop_ksplit", 1, N, Tn, 2), lambda: H.call(
+                "nppc_lstm2_bwd_coop2_head", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dyt, whT, packed_bwd.kwb1,
+                packed_bwd.kwb2, dx, dg1, dg2, xch, xch.numel() * xch.element_size(), flags, N, Tn, _n_cu(), H.stream()))
+            return dx, dg1, dg2
         _timed(("lstm2_bwd_coop_ksplit", 1, N, Tn, 2), lambda: H.call(
             "nppc_lstm2_bwd_coop2", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2, packed_bwd.kwb1, packed_bwd.kwb2,
             dx, dg1, dg2, xch, xch.numel() * xch.element_size(), flags, N, Tn, _n_cu(), H.stream()))
         return dx, dg1, dg2
+    assert head is None, "the fused head backward needs the K-split cooperative kernel"
     if use_coop:
         ncl = (N + 31) // 32
         xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 768,), dt, dev)

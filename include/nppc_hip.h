@@ -158,6 +158,16 @@ int nppc_lstm2_coop_bwd2_pack(const float* w_ih0, const float* w_hh0, const floa
 int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* wb1,
                          const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
                          int Tn, int n_cu, void* stream);
+/* the same with the head backward fused: instead of dh2 the kernel takes the dY rows dyt [Tn][N][16] bf16
+ * (nppc_head_dy_gather: dout [B'][O][Fo][Tn - la] -> rows, zero beyond O and before the look-ahead) and the packed head
+ * weights whT [H][32] ([u][o]) and forms d h2 += dY . Wh itself; nppc_sb_head_bwd_w is the weight / bias half of
+ * nppc_sb_head_bwd (no dh2 output). */
+int nppc_lstm2_bwd_coop2_head(const void* g1, const void* g2, const void* c1, const void* c2, const void* dyt, const void* whT,
+                              const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes,
+                              unsigned* flags, long N, int Tn, int n_cu, void* stream);
+int nppc_head_dy_gather(const float* dout, void* dyt, long Nseq, int Tn, int la, int O, int Fo, void* stream);
+int nppc_sb_head_bwd_w(int prec, const float* dout, const void* h2, float* dWh, float* dbh, long Nseq, int Tn, int la, int Hd,
+                       int O, int Fo, void* stream);
 int nppc_lstm2_bwd_packed_elems(int I, int H, long* n1, long* n2);
 int nppc_lstm2_pack_weights_bwd(int prec, const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
                                 int I, int H, void* wb1, void* wb2, void* stream);

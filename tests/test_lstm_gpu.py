@@ -255,3 +255,50 @@ def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
         assert float((got2 - want2).abs().max()) < 2e-5 * max(1.0, float(want2.abs().max()))
         for k in ("h1", "h2", "c1", "c2", "g1", "g2"):
             assert torch.equal(tr[k], ref_state[k]), k
+
+
+@pytest.mark.parametrize("N,Tn,O,Fo,la", [(96, 7, 10, 48, 2), (77, 5, 4, 77, 0), (256, 6, 16, 128, 1)])
+def test_fused_head_backward_equals_separate_kernels(N, Tn, O, Fo, la):
+    """K-split backward forming d h2 = dY . Wh itself (dY rows by LDS-DMA, two MFMAs per wave and step) against the
+    head_bwd_dh kernel + the dh2-reading kernel; ragged last cluster, look-ahead rows, O up to one MFMA tile"""
+    from nppc_audio import _hip as H
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import PackedLSTM, PackedLSTMBwd, bwd_head_fusable, lstm2_backward, lstm2_forward
+    I, Hd = 34, 384
+    P = _weights(I, Hd, 4)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in names])
+    pb = PackedLSTMBwd(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")])
+    assert bwd_head_fusable(N, pb, coop=True)
+    g = torch.Generator().manual_seed(N + O)
+    xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
+    xt[:, :, :I] = torch.randn(Tn, N, I, generator=g).to(dev)
+    saved = lstm2_forward(xt, pk, True, 1)
+    Bq = N // Fo
+    dout = torch.randn(Bq, O, Fo, Tn - la, generator=g).to(dev)
+    wh = (torch.randn(O, Hd, generator=g) * 0.2)
+    whT = torch.zeros(Hd, 32, dtype=torch.bfloat16, device=dev)
+    whT[:, :O] = wh.t().to(dev)
+    s = H.stream()
+    dh2 = torch.empty(Tn, N, Hd, dtype=torch.bfloat16, device=dev)
+    dW, db = torch.zeros(O, Hd, device=dev), torch.zeros(O, device=dev)
+    H.call("nppc_sb_head_bwd", 0, dout, whT, saved["h2"], dh2, dW, db, N, Tn, la, Hd, O, Fo, s)
+    a = [t.clone() for t in lstm2_backward(saved, dh2, pb, pk.kx, coop=True)]
+    dyt = torch.full((Tn, N, 16), float("nan"), dtype=torch.bfloat16, device=dev)
+    H.call("nppc_head_dy_gather", dout, dyt, N, Tn, la, O, Fo, s)
+    dW2, db2 = torch.zeros(O, Hd, device=dev), torch.zeros(O, device=dev)
+    H.call("nppc_sb_head_bwd_w", 0, dout, saved["h2"], dW2, db2, N, Tn, la, Hd, O, Fo, s)
+    b = [t.clone() for t in lstm2_backward(saved, None, pb, pk.kx, coop=True, head=(dyt, whT))]
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    # the gathered rows: exact bf16 of dout, zero padding
+    want_rows = torch.zeros(Tn, N, 16)
+    want_rows[la:, :, :O] = dout.cpu().permute(3, 0, 2, 1).reshape(Tn - la, N, O)
+    assert torch.equal(dyt.float().cpu(), want_rows.to(torch.bfloat16).float())
+    assert torch.allclose(dW2, dW, rtol=1e-5, atol=1e-5) and torch.allclose(db2, db, rtol=1e-5, atol=1e-5)
+    for name, x, y in zip(("dx", "dg1", "dg2"), a, b):
+        x, y = x.float(), y.float()
+        assert bool(torch.isfinite(y).all()), name
+        assert float((x - y).abs().max()) < 2e-2 * float(x.abs().max()) + 1e-6, name     # dh2 rounded to bf16 on one side only
