@@ -1,18 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: NPPC K=5 FullSubNet+ train step, spectrogram-frames/s on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5]
 
-One "step" = one full train step of BASELINE config C2 on one minibatch of synthetic 16 kHz noisy speech that is
-already resident in HBM: noisy+clean STFT, frozen FullSubNet+ restorer forward, cIRM build/apply, K=5 direction net
-forward, Gram-Schmidt, NPPC loss, full backward, gradient all-reduce (N > 1), Adam.  Weak scaling: every rank runs
-the C2 per-GPU batch (32 x 4 s), rank r on clips [32r, 32r+32).  Weights: seeded random init (no checkpoint offline).
+N > 1 without an external launcher: bench.py starts its own N ranks (`python -m torch.distributed.run ... bench.py`) as a
+CHILD process before anything touches the GPU and exits with the child's code; under an external torch.distributed.run
+(WORLD_SIZE set) it is a rank.
+
+One "step" (c2, the default = BASELINE config 2; c5 = config 5: 8 x 30 s, K=8) = one full train step on one minibatch
+of synthetic 16 kHz noisy speech that is already resident in HBM: noisy+clean STFT, frozen FullSubNet+ restorer
+forward, cIRM build/apply, K-direction net forward, Gram-Schmidt, NPPC loss, full backward, gradient all-reduce
+(N > 1), Adam.  Weak scaling: every rank runs the per-GPU batch, rank r on clips [B*r, B*r+B).  Weights: seeded random
+init (no checkpoint offline).  --config c3 = BASELINE config 3 (inpainting sibling, single GPU), same JSON schema.
 Prints ONE JSON line on rank 0.
+
+What the line's extra objects mean (definitions and byte/FLOP counts: DESIGN.md section 4):
+  roofline        the kernel with the largest total duration per step (HIP events around every launch in an untimed
+                  pass rank the kernels; `achieved` of an LSTM kernel comes from HIP events inside the TIMED region);
+                  on a < 1 % tie the lower fraction is reported.  roofline.step = whole-step algorithmic FLOP rate.
+  roofline.hbm_families   achieved GB/s of the HBM-bound kernel families = algorithmic bytes / HIP-event time
+  fp32            the precision-matched (reference dtype) step time, a few steps outside the timed region
+  cpu_baseline    the oracle (CPU restatement pinned to the reference by tests/golden) on a bounded sample
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -23,9 +38,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "generative-audio_amd"))
 
 BATCH, SECONDS, SR, K_DIRS = 32, 4, 16000, 5
-NFFT, HOP = 512, 256
+NFFT, HOP, NF = 512, 256, 257
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PEAK_F32_TFLOPS = 157.3
+PEAK_F32_TFLOPS = 157.3       # fp32 matrix (= vector) peak
+PEAK_HBM_GBS = 8000.0
+PMC_CSV = os.path.join(ROOT, "profiles", "r02_bench_c2_bf16_pmc_traffic.csv")
+PMC_STAMP = os.path.join(ROOT, "profiles", "r02_bench_c2_bf16_pmc_stamp.json")
 
 
 def build_trainer(precision, rank, world, batch, length, n_dirs=K_DIRS):
@@ -72,34 +90,46 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def pmc_traffic(dom_name):
-    """HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) from the committed
-    rocprofv3 counter passes of this same command (profiles/r01_bench_c2_bf16_pmc_traffic.csv, tools/summarize_pmc.py):
-    counters cannot be collected from inside the timed process, so the figure is null when that file is absent or the
-    run is not the default C2 configuration it was measured on."""
+def kernel_source_hash():
+    """identifies the kernel sources of the running tree (the GPU box has no .git): sha256 over csrc + the C header"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "generative-audio_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/nppc_hip.h"]:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(rocprof_pattern, workload):
+    """HBM bytes per launch of a kernel (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) from the committed rocprofv3
+    counter passes of this same command (tools/summarize_pmc.py; counters cannot be collected from inside the timed
+    process).  The passes are stamped with the hash of the kernel sources they profiled: a different running tree, a
+    different workload or a missing file gives null."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_bench_c2_bf16_pmc_traffic.csv")
-    key = {"lstm2_bwd_coop_ksplit": "lstm2_coop_bwd2_kernel", "lstm2_fwd_coop_g2[N=8224": "2, 5, 64, false",
-           "lstm2_fwd_coop_g2[N=4096": "2, 2, 64, true"}
-    pat = next((v for k, v in key.items() if dom_name.startswith(k)), None)
-    if pat is None or not os.path.exists(path) or "N=8224" not in dom_name and "N=4096" not in dom_name:
+    if workload != "C2" or rocprof_pattern is None or not (os.path.exists(PMC_CSV) and os.path.exists(PMC_STAMP)):
         return None, "no committed PMC pass for this kernel / configuration"
-    with open(path) as f:
+    stamp = json.load(open(PMC_STAMP))
+    if stamp.get("kernel_source_hash") != kernel_source_hash():
+        return None, (f"committed PMC pass profiled kernel sources {stamp.get('kernel_source_hash')} (git {stamp.get('git_head')}), "
+                      f"the running tree is {kernel_source_hash()}: stale, not reported")
+    with open(PMC_CSV) as f:
         for r in csv.DictReader(f):
-            if pat in r["kernel"]:
+            if rocprof_pattern in r["kernel"]:
                 mb = float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])
-                return mb * 1048576.0, "bytes per launch, profiles/r01_bench_c2_bf16_pmc_traffic.csv (separate --pmc passes)"
+                return mb * 1048576.0, (f"bytes per launch, {os.path.relpath(PMC_CSV, ROOT)} (separate --pmc passes, git "
+                                        f"{stamp.get('git_head')}, kernel sources {stamp.get('kernel_source_hash')})")
     return None, "kernel not in the committed PMC summary"
 
 
 def cpu_baseline():
     """Reference-shaped CPU path (the oracle restatement, pinned to the reference by tests/golden) on a bounded
-    sample: B=4 x 4 s, K=5, G_pc=2, one full train step (forward x [2 restorer, 3 STFT] + backward + Adam)."""
+    sample: B=4 x 4 s, K=5, G_pc=2, full train steps (forward x [2 restorer, 3 STFT] + backward + Adam): one warm-up on a
+    0.25 s crop, then 2 timed steps."""
     sys.path.insert(0, ROOT)
     from oracle import nppc_ref as R
     from oracle import weights as W
     torch.set_num_threads(host_cores())
-    B, L = 4, SECONDS * SR
+    B, L, NT = 4, SECONDS * SR, 2
     spec = W.nppc_spec(K_DIRS)
     P = {k: torch.from_numpy(v) for k, v in W.make_weights(spec, 7).items()}
     train = {k: v.requires_grad_(True) for k, v in P.items() if k.startswith("audio_pc_wrapper")}
@@ -115,12 +145,96 @@ def cpu_baseline():
 
     one(0, noisy[:, :4096], clean[:, :4096])                  # thread-pool / allocator warm-up on a 0.25 s crop
     t0 = time.perf_counter()
-    one(1, noisy, clean)
-    dt = time.perf_counter() - t0
+    for i in range(NT):
+        one(1 + i, noisy, clean)
+    dt = (time.perf_counter() - t0) / NT
     frames = B * (1 + L // HOP)
     return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step, B={B} x {SECONDS} s, K={K_DIRS}, G_pc=2, fp32, reference-shaped "
-                      f"(2x restorer, 3x STFT), {dt:.1f} s"}
+            "sample": f"{NT} train steps, B={B} x {SECONDS} s, K={K_DIRS}, G_pc=2, fp32, reference-shaped "
+                      f"(2x restorer, 3x STFT), {dt:.1f} s/step"}
+
+
+# ------------------------------------------------------------------------------------------------ algorithmic work
+LSTM_FLOP_PER_SEQ_STEP = 2 * 4 * 384 * (34 + 384) + 2 * 4 * 384 * (2 * 384)        # both layers' gate GEMMs
+
+
+def step_flops(B, T, K, g_pc=2):
+    """restorer forward x1 + direction net forward x3 (forward + 2x for backward)"""
+    Tv = T + 2
+    fo = NF if (g_pc <= 1 or B == 1) else (NF - NF % g_pc) // g_pc
+    tcn = lambda C: 3 * (8 * (2048 * C + 3072) + 2 * C * NF)
+    rest = B * NF * Tv * (LSTM_FLOP_PER_SEQ_STEP + 2 * 384 * 2) + B * Tv * tcn(NF)
+    pc = B * fo * Tv * (LSTM_FLOP_PER_SEQ_STEP + 2 * 384 * 2 * K) + B * Tv * tcn(2 * NF)
+    return rest + 3 * pc
+
+
+def hbm_family_bytes(B, L, T, K, n_params, act_bytes, g_pc=2):
+    """algorithmic bytes per step of the HBM-bound kernel families (TCN element-wise: DESIGN.md section 4)
+    -> {family: (bytes, [entry points])}"""
+    Tv = T + 2
+    fo = NF if (g_pc <= 1 or B == 1) else (NF - NF % g_pc) // g_pc
+    m = B * NF * T * 4                                 # one fp32 spectrogram map
+    W = B * K * 2 * fo * T * 4                         # the K directions
+    E = B * 2 * fo * T * 4                             # one cIRM in drop-band order
+    act = 3 * B * Tv * 512 * act_bytes                 # one hidden TCN activation, three branches
+    return {
+        "stft": (2 * B * L * 4 + 5 * m, ["nppc_stft"]),
+        "cirm_build_compress": (6 * m, ["nppc_cirm_build_compress"]),
+        "cirm_decompress_apply": (7 * m, ["nppc_cirm_decompress_apply_conj"]),
+        # 4 source maps per net read once (the unfolded tensor is never algorithmic traffic), both nets
+        "subband_staging_fwd": (2 * 4 * B * NF * Tv * 4, ["nppc_subband_mean", "nppc_subband_stage"]),
+        "gs_and_loss": (5 * W + 3 * E, ["nppc_gram", "nppc_combine", "nppc_gs_solve", "nppc_gs_bwd_solve", "nppc_loss_solve",
+                                        "nppc_loss_solve_eps", "nppc_loss_bwd_coef", "nppc_loss_bwd_coef_dev"]),
+        "adam": (7 * 4 * n_params, ["nppc_adam_step"]),
+        # per TCN block: forward reads the 1x1-conv output once and writes the depthwise output once (both nets);
+        # backward reads the upstream gradient + the two saved activations and writes one gradient (direction net)
+        "tcn_elementwise": (8 * (2 * 2 * act + 4 * act), ["nppc_tcn_dwconv", "nppc_tcn_gn_apply", "nppc_tcn_gn_bwd",
+                                                          "nppc_tcn_dwconv_bwd", "nppc_tcn_mid_fwd", "nppc_tcn_mid_bwd",
+                                                          "nppc_tcn_mid_bwd_reduce"]),
+    }
+
+
+ROCPROF_NAME = {   # bench label prefix -> substring of the rocprofv3 kernel name (template arguments included)
+    "lstm2_bwd_coop_ksplit": "lstm2_coop_bwd2_kernel",
+    "lstm2_fwd_coop_g2[N=8224": "2, 5, 64, false",
+    "lstm2_fwd_coop_g2_train[N=4096": "2, 2, 64, true",
+}
+
+
+def self_launch(a):
+    """--gpus N without an external launcher: start the N ranks as a child torch.distributed.run BEFORE any GPU call of
+    this process (a process that initialised the GPU must never exec / must not hold the device the ranks need)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"starting {a.gpus} ranks: {' '.join(cmd[1:])}")
+    return subprocess.call(cmd, env=env)
+
+
+def dp_selftest(a, world, rank):
+    """CPU rehearsal of the launcher + the gradient exchange (gloo): what tests/test_dp_gloo_cpu.py drives"""
+    import torch.distributed as dist
+    from nppc_audio.dp import FlatGradientReducer
+    dist.init_process_group("gloo")
+    if a.dp_selftest_fail_rank == rank:
+        raise SystemExit(3)
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = FlatGradientReducer()
+    red.range_ready(g, 700, 1000)
+    red.range_ready(g, 100, 300)
+    scale = red.finish(g)
+    want = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
+    ok = bool(torch.allclose(g * scale, want))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dp_selftest": ok, "n_gpus": world, "scale": scale}))
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 4)
 
 
 def main():
@@ -128,27 +242,49 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help="BASELINE.json config (c2 = headline)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--seconds", type=float, default=SECONDS)
-    ap.add_argument("--dirs", type=int, default=K_DIRS, help="number of PC directions K (config C5 uses 8)")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seconds", type=float, default=None)
+    ap.add_argument("--dirs", type=int, default=None, help="number of PC directions K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the precision-matched fp32 steps")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-launch HIP-event pass")
+    ap.add_argument("--dp-selftest", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dp-selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dp_selftest:
+        return dp_selftest(a, world, rank)
+    if a.config == "c3":
+        if world > 1:
+            raise SystemExit("config c3 (inpainting) is single-GPU: train-mode BatchNorm couples the minibatch (DESIGN.md 8)")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_inpainting
+        return bench_inpainting.main(["--steps", str(a.steps), "--warmup", str(a.warmup), "--precision", a.precision]
+                                     + (["--no-cpu-baseline"] if a.no_cpu_baseline else []))
+    cb, cs, ck = {"c2": (BATCH, SECONDS, K_DIRS), "c5": (8, 30, 8)}[a.config]
+    a.batch, a.seconds, a.dirs = a.batch or cb, a.seconds or cs, a.dirs or ck
+    workload = {(BATCH, SECONDS, K_DIRS): "C2", (8, 30, 8): "C5"}.get((a.batch, a.seconds, a.dirs), "custom")
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call: dmabuf IPC for RCCL
     torch.cuda.set_device(local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    from nppc_audio import _hip as H
     from nppc_audio import ops_lstm
     length = int(a.seconds * SR)
     tr, batch = build_trainer(a.precision, rank, world, a.batch, length, a.dirs)
-    frames = a.batch * (1 + length // HOP)
+    T = 1 + length // HOP
+    frames = a.batch * T
 
     def sync():
         if world > 1:
@@ -173,51 +309,110 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
+    nto = ops_lstm.coop_timeouts()      # sticky counter: covers every launch since the process started
+    if nto:      # a bounded hand-off spin gave up: the step's results are wrong, so is any number measured on them
+        raise RuntimeError(f"rank {rank}: {nto} cooperative LSTM hand-off time-outs during the run: measurement invalid")
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    ms_step = 1e3 * dt / a.steps
+    log(f"timed region done: {ms_step:.2f} ms/step")
 
-    # dominant kernel: the fused 2-layer LSTM recurrence (forward instances + the backward recurrence)
+    # ---- LSTM launches inside the timed region (HIP events on the launch stream) --------------------------------
     per = {}
     for label, e0, e1 in prof:
         per.setdefault(label, []).append(e0.elapsed_time(e1))
     kern = {}
-    H_, I_ = 384, 34
     for (name, train, N, Tn, mt), ms in per.items():
         avg = sum(ms) / len(ms)
-        flops = N * Tn * (2 * 4 * H_ * (I_ + H_) + 2 * 4 * H_ * (2 * H_))      # algorithmic: both layers' gate GEMMs
-        kern[f"{name}{'_train' if train and name.endswith('fwd') else ''}[N={N},T'={Tn},mtile={mt}]"] = dict(
-            ms=avg, tflops=flops / (avg * 1e-3) / 1e12)
-    dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"]) if kern else ("none", dict(ms=0.0, tflops=0.0))
+        lab = f"{name}{'_train' if train and 'fwd' in name else ''}[N={N},T'={Tn},mtile={mt}]"
+        kern[lab] = dict(ms=avg, launches_per_step=len(ms) / a.steps, tflops=N * Tn * LSTM_FLOP_PER_SEQ_STEP / (avg * 1e-3) / 1e12)
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+
+    # ---- untimed pass with HIP events around EVERY launch: ranks the kernels, times the HBM-bound families -------
+    totals, fam = {}, None
+    if not a.no_families:
+        NP = 3
+        H.PROFILE = []
+        for _ in range(NP):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        calls, H.PROFILE = H.PROFILE, None
+        for name, e0, e1 in calls:
+            t = totals.setdefault(name, [0.0, 0])
+            t[0] += e0.elapsed_time(e1) / NP
+            t[1] += 1
+        n_params = tr.nppc_model.audio_pc_wrapper.net.engine().fp.flat.numel()
+        fam = {}
+        for f, (nbytes, names) in hbm_family_bytes(a.batch, length, T, a.dirs, n_params, 2 if a.precision == "bf16" else 4).items():
+            ms = sum(totals[n][0] for n in names if n in totals)
+            if ms > 0:
+                fam[f] = dict(algorithmic_MB=nbytes / 1e6, ms_per_step=ms, launches_per_step=sum(totals[n][1] for n in names if n in totals) / NP,
+                              achieved_GBps=nbytes / (ms * 1e-3) / 1e9, frac_of_hbm_peak=nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
+        log(f"per-launch pass done: {sum(v[1] for v in totals.values()) // NP} launches/step")
+
+    # dominant kernel = largest TOTAL duration per step; LSTM launches are told apart by shape (different template
+    # instantiations = different kernels in a rocprof summary), everything else by entry point
+    rank_ms = {lab: v["ms"] * v["launches_per_step"] for lab, v in kern.items()}
+    for name, (ms, _) in totals.items():
+        if not name.startswith("nppc_lstm2_") or "pack" in name:
+            rank_ms[name] = ms
+    ordered = sorted(rank_ms.items(), key=lambda kv: -kv[1])
+    dom_name = ordered[0][0] if ordered else "none"
+    if len(ordered) > 1 and ordered[1][1] > 0.99 * ordered[0][1] and ordered[0][0] in kern and ordered[1][0] in kern:
+        # a < 1 % tie between two LSTM kernels: report the one further from its roofline
+        dom_name = min(ordered[:2], key=lambda kv: kern[kv[0]]["tflops"])[0]
+    flops_step = step_flops(a.batch, T, a.dirs)
+    roof = {"bound": "mfma", "kernel": dom_name, "peak": peak, "unit": "TFLOP/s", "traffic": None,
+            "ranked_ms_per_step": {k: round(v, 3) for k, v in ordered[:12]},
+            "all_lstm_kernels": kern,
+            "step": {"algorithmic_flop": flops_step, "achieved": flops_step / (ms_step * 1e-3) / 1e12,
+                     "frac": flops_step / (ms_step * 1e-3) / 1e12 / peak}}
+    if dom_name in kern:
+        d = kern[dom_name]
+        roof.update(achieved=d["tflops"], frac=d["tflops"] / peak, avg_ms=d["ms"])
+        pat = next((v for k, v in ROCPROF_NAME.items() if dom_name.startswith(k)), None)
+        roof["traffic"], roof["traffic_note"] = pmc_traffic(pat, workload)
+    else:
+        roof.update(achieved=None, frac=None, avg_ms=rank_ms.get(dom_name))
+    if fam is not None:
+        roof["hbm_families"] = fam
+
     out = {
-        "metric": "spectrogram-frames/sec, NPPC K=5 FullSubNet+ train step",
+        "metric": f"spectrogram-frames/sec, NPPC K={a.dirs} FullSubNet+ train step",
         "value": world * frames * a.steps / dt,
         "unit": "frames/s",
         "per_gpu": frames * a.steps / dt,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps,
+        "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"{'C2' if (a.batch, a.seconds, a.dirs) == (BATCH, SECONDS, K_DIRS) else ('C5' if (a.batch, a.seconds, a.dirs) == (8, 30, 8) else 'custom')}: speech-enhancement NPPC, FullSubNet+ restorer + K={a.dirs} direction net, "
+        "config": {"workload": f"{workload}: speech-enhancement NPPC, FullSubNet+ restorer + K={a.dirs} direction net, "
                                f"batch={a.batch}x{a.seconds:g}s@16kHz per GPU, STFT {NFFT}/{HOP}, G_rest=1 G_pc=2, "
                                f"full train step (fwd+loss+bwd+Adam{'+RCCL all-reduce' if world > 1 else ''})",
                    "global_batch": a.batch * world, "frames_per_step_per_gpu": frames,
                    "parallelism": f"dp{world}", "objective_last": float(objective)},
-        "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                     "frac": dom["tflops"] / peak, "avg_ms": dom["ms"], "traffic": None,
-                     "all_lstm_kernels": kern},
+        "roofline": roof,
+        "lstm_handoff_timeouts": 0,
     }
-    log(f"timed region done: {1e3 * dt / a.steps:.1f} ms/step")
-    tr_bytes, tr_src = pmc_traffic(dom_name)
-    out["roofline"]["traffic"] = tr_bytes
-    out["roofline"]["traffic_note"] = tr_src
-    from nppc_audio import ops_lstm
-    nto = ops_lstm.coop_timeouts()
-    if nto:      # a bounded hand-off spin gave up: the step's results are wrong, so is any number measured on them
-        raise RuntimeError(f"{nto} cooperative LSTM hand-off time-outs during the run: measurement invalid")
-    out["lstm_handoff_timeouts"] = 0
+    if world == 1 and a.precision == "bf16" and not a.no_fp32:
+        # the reference computes in fp32: the same step in the product's fp32 parity mode (exact-f32 MFMA), outside the
+        # timed region.  The bf16 trainer's step-persistent workspaces stay allocated (288 GB of HBM: both fit).
+        log("timing the fp32 parity mode (1 warm-up + 3 steps)")
+        tr32, batch32 = build_trainer("fp32", 0, 1, a.batch, length, a.dirs)
+        tr32.train_step(batch32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tr32.train_step(batch32)
+        torch.cuda.synchronize()
+        ms32 = 1e3 * (time.perf_counter() - t0) / 3
+        ops_lstm.check_coop_timeouts("fp32 steps")
+        out["fp32"] = {"ms_per_step": ms32, "frames_per_s": frames / (ms32 * 1e-3), "steps": 3,
+                       "achieved_tflops": flops_step / (ms32 * 1e-3) / 1e12,
+                       "frac_of_fp32_matrix_peak": flops_step / (ms32 * 1e-3) / 1e12 / PEAK_F32_TFLOPS}
+        del tr32, batch32
     if world == 1 and not a.no_cpu_baseline:
         log("timing the CPU baseline (bounded sample)")
         out["cpu_baseline"] = cpu_baseline()

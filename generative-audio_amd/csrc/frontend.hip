@@ -254,6 +254,7 @@ static int ew_grid(size_t total) {
 // One workgroup per clip, three passes over the clip (sums, mix + peak, rescale); fp64 sums.
 __global__ __launch_bounds__(256) void mix_snr_kernel(const float* __restrict__ clean, const float* __restrict__ noise,
                                                       const float* __restrict__ snr_db, float target_dbfs,
+                                                      const float* __restrict__ target_item,
                                                       float* __restrict__ noisy_out, float* __restrict__ clean_out, int L) {
   __shared__ double red[3][4];
   __shared__ float bc[3];
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void mix_snr_kernel(const float* __restrict__ 
     const double pn = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / L;
     const float rms = (float)sqrt(pc);
     const float rms_db = 20.f * log10f(rms + 1e-8f);
-    const float gain = powf(10.f, (target_dbfs - rms_db) / 20.f);
+    const float gain = powf(10.f, ((target_item ? target_item[b] : target_dbfs) - rms_db) / 20.f);
     const float clean_power = (float)pc * gain * gain;
     const float snr_lin = powf(10.f, snr_db[b] / 10.f);
     bc[0] = gain;
@@ -497,11 +498,11 @@ int nppc_istft(const float* re, const float* im, float* out, int B, int T, int n
   return NPPC_OK;
 }
 
-int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, float* noisy_out,
-                 float* clean_out, int B, int L, void* stream) {
+int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, const float* target_item,
+                 float* noisy_out, float* clean_out, int B, int L, void* stream) {
   if (!clean || !noise || !snr_db || !noisy_out || !clean_out || B <= 0 || L <= 0) return NPPC_EBADARG;
-  hipLaunchKernelGGL(mix_snr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, noise, snr_db, target_dbfs, noisy_out,
-                     clean_out, L);
+  hipLaunchKernelGGL(mix_snr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, noise, snr_db, target_dbfs, target_item,
+                     noisy_out, clean_out, L);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -10,7 +10,10 @@
 //             every wave reads the payload with sc1 buffer loads
 // Correctness never depends on placement or dispatch order; all G workgroups of a cluster must be co-resident, which
 // the host guarantees by launching <= one workgroup per CU (grid <= CU count, LDS request > half a CU).
-// Every spin is bounded: on timeout a word in the flag block is set and the workgroup carries on (wrong numbers, no hang).
+// Every spin is bounded: on time-out the workgroup adds 1 to the STICKY time-out counter -- the word right behind the
+// epoch words of the caller's flag block -- and carries on (wrong numbers, no hang).  The launchers zero the epoch words
+// only: the counter survives later launches and is cleared by the caller alone (ops_lstm.clear_coop_timeouts), so a host
+// check at any later point (trainer log interval, end of bench) still sees a time-out of ANY earlier launch.
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -43,7 +46,7 @@ struct CoopArgs {
   void* h2;           // [Tn][N][H]
   void* h1; void* g1; void* g2; void* c1; void* c2;   // train: h1 [Tn][N][H] like h2
   void* xch;          // [clusters][2 layers][2 parities][G][MC][HC]  exchange slices
-  unsigned* flags;    // [clusters][2 layers][G] epochs, then 1 timeout word; zeroed before every launch
+  unsigned* flags;    // [clusters][2 layers][G] epochs (zeroed before every launch), then the sticky time-out counter
   long N; int Tn; int clusters;
   // fused output head (inference): whp [16][H] row-major (rows >= O zero), hpart [G][Tn][N][O] fp32 partial sums of
   // sum_u h2[t][n][u] * Wh[o][u] over the units of CU g; whp == nullptr: h2 is stored instead
@@ -296,7 +299,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         while (__hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       while (__hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > SPIN_LIMIT) {
-          __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
         while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
         while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
@@ -1252,7 +1255,7 @@ static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
       hipSuccess)
     return NPPC_ELAUNCH;
-  if (hipMemsetAsync(a.flags, 0, ((size_t)a.clusters * 2 * G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  if (hipMemsetAsync(a.flags, 0, (size_t)a.clusters * 2 * G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   // G = 2: grid rounded up to a multiple of 8 for the XCD-aware placement (coop_ids); spare workgroups exit at once
   const int grid = G == 2 ? round_up(a.clusters * G, 8) : a.clusters * G;
   hipLaunchKernelGGL(k, dim3(grid), dim3((H / G / 16) * 64), smem, s, a);
@@ -1364,7 +1367,7 @@ int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const vo
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm2_coop_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)smem) != hipSuccess)
     return NPPC_ELAUNCH;
-  if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, (size_t)clusters * 2 * CB_G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   hipLaunchKernelGGL(lstm2_coop_bwd_kernel, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
@@ -1404,7 +1407,7 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)
                       : reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<false>);
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return NPPC_ELAUNCH;
-  if (hipMemsetAsync(flags, 0, ((size_t)clusters * 2 * CB_G + 4) * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, (size_t)clusters * 2 * CB_G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   if (dyt)
     hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<true>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   else

@@ -17,17 +17,20 @@ __device__ __forceinline__ int reflect_idx(int i, int F) {
 
 // scale[b] = 1 / (mean over (F, 2n+1+3, T') of the concatenated sub-band input + 1e-5)
 // sum of the unfolded part = sum_f mult[f] * src[f]  (mult = how many windows contain bin f after reflection)
-// grid (SM_CHUNKS, B): every workgroup sums a slice of the frames; the last one to arrive for sample b (device counter)
-// turns the fp64 total into the scale and re-arms the accumulators (one workgroup per sample left 224 CUs idle)
-constexpr int SM_CHUNKS = 16, SM_MAXB = 1024;
-__device__ double g_sm_acc[SM_MAXB];
-__device__ unsigned g_sm_cnt[SM_MAXB];
+// grid (SM_CHUNKS, B): every workgroup sums a slice of the frames; the last one to arrive for sample b (arrival counter)
+// turns the fp64 total into the scale and re-arms the accumulators (one workgroup per sample left 224 CUs idle).
+// Accumulators and counters live in the CALLER's workspace `work` (2*B 8-byte words: B fp64 sums, then B counters,
+// zero-initialised once by the caller), so launches on different workspaces may overlap freely.
+constexpr int SM_CHUNKS = 16;
 
 template <typename T>
 __global__ __launch_bounds__(256) void subband_mean_kernel(const T* __restrict__ src, int ldS, const T* __restrict__ fb,
                                                            int ldF, long strideFb, const float* __restrict__ mult,
-                                                           float* __restrict__ scale, int F, int Tp, int Tv, int nfeat) {
+                                                           float* __restrict__ scale, double* __restrict__ work, int F,
+                                                           int Tp, int Tv, int nfeat) {
   __shared__ double red[4];
+  double* g_sm_acc = work;
+  unsigned* g_sm_cnt = reinterpret_cast<unsigned*>(work + gridDim.y);
   const int b = blockIdx.y, tid = threadIdx.x;
   const int tper = (Tv + gridDim.x - 1) / gridDim.x;
   const int ta = blockIdx.x * tper, tb = ta + tper < Tv ? ta + tper : Tv;
@@ -46,12 +49,12 @@ __global__ __launch_bounds__(256) void subband_mean_kernel(const T* __restrict__
   if (tid == 0) {
     atomicAdd(&g_sm_acc[b], red[0] + red[1] + red[2] + red[3]);
     __threadfence();
-    if (atomicAdd(&g_sm_cnt[b], 1u) == gridDim.x - 1) {
+    if (atomicAdd(&g_sm_cnt[2 * b], 1u) == gridDim.x - 1) {
       const double tot = atomicAdd(&g_sm_acc[b], 0.0);
       const float mu = (float)(tot / ((double)F * nfeat * Tv));
       scale[b] = 1.0f / (mu + 1e-5f);
       g_sm_acc[b] = 0.0;
-      g_sm_cnt[b] = 0u;
+      g_sm_cnt[2 * b] = 0u;
       __threadfence();
     }
   }
@@ -205,17 +208,16 @@ int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* o
 
 
 int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* mult,
-                      float* scale, int B, int F, int Tp, int Tv, int nfeat, void* stream) {
-  if (!src || !fb || !mult || !scale || B <= 0) return NPPC_EBADARG;
-  if (B > SM_MAXB) return NPPC_EUNSUPPORTED;
+                      float* scale, double* work, int B, int F, int Tp, int Tv, int nfeat, void* stream) {
+  if (!src || !fb || !mult || !scale || !work || B <= 0) return NPPC_EBADARG;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(Tv < SM_CHUNKS ? Tv : SM_CHUNKS, B);
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(subband_mean_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, ldS, (const bf16_t*)fb, ldF,
-                       strideFb, mult, scale, F, Tp, Tv, nfeat);
+                       strideFb, mult, scale, work, F, Tp, Tv, nfeat);
   else
     hipLaunchKernelGGL(subband_mean_kernel<float>, grid, dim3(256), 0, s, (const float*)src, ldS, (const float*)fb, ldF,
-                       strideFb, mult, scale, F, Tp, Tv, nfeat);
+                       strideFb, mult, scale, work, F, Tp, Tv, nfeat);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -116,6 +116,9 @@ class FSNEngine:
         self.sP = flat.branch_stride()
         self.packed_version = None
         self._side = None                     # side stream for the LSTM weight-gradient GEMMs (backward)
+        self._gen = 0                         # train-forward generation: backward must consume the LATEST train forward
+        self.last_train = None
+        self.grad_range_hook = None           # fn(flat_grad, lo, hi): range final for this step (dp.FlatGradientReducer)
         self.bufs = {}
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
         self.KX = self.lstm.kx
@@ -204,6 +207,7 @@ class FSNEngine:
         if self.nm == 2:
             d["rawmag"] = torch.zeros(B, Tp, self.ldF, dtype=dt, device=dev)
         d["sbscale"] = torch.empty(B, dtype=torch.float32, device=dev)
+        d["sbwork"] = torch.zeros(2 * B, dtype=torch.float64, device=dev)     # nppc_subband_mean: sums + arrival counters
         G = self.G if B > 1 else 1
         Fo = self.F if G <= 1 else (self.F - self.F % G) // G
         d["G"], d["Fo"], d["Nseq"] = G, Fo, B * Fo
@@ -287,8 +291,8 @@ class FSNEngine:
             src, ldS = d["X"][0, 0], ldC          # attention-scaled, normalised magnitude (fullsubnet_plus.py:203)
         else:
             src, ldS = d["rawmag"], ldF           # RAW padded magnitude (networks.py:133)
-        H.call("nppc_subband_mean", prec, src, ldS, d["fb"], ldF, R * ldF, self.mult, d["sbscale"], B, F, Tp, Tv,
-               self.I, s)
+        H.call("nppc_subband_mean", prec, src, ldS, d["fb"], ldF, R * ldF, self.mult, d["sbscale"], d["sbwork"], B, F, Tp,
+               Tv, self.I, s)
         H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
                self.nb, self.G, self.KX, int(train), s)
         # 7: two-layer LSTM over T' steps for the B*F' sequences
@@ -305,6 +309,10 @@ class FSNEngine:
             H.call("nppc_sb_head", prec, lo["h2"], self.Whp, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
                    self.la, self.Hd, self.O, d["Fo"], s)
         self.last = d
+        if train:
+            self._gen += 1
+            d["gen"] = self._gen
+            self.last_train = d
         return out
 
     # ------------------------------------------------------------------ backward (direction net)
@@ -390,10 +398,24 @@ class FSNEngine:
             H.call("nppc_gemm_nt_splitk", self.prec, A, Rp, inT, Rp, slab, wp, K4p, wp, Rp, 1, s)
             scatter(slab, 1, K4p, wp, dest)
 
-    def backward(self, dout):
-        """dout [B', O, F', T] fp32 -> flat parameter gradient (same layout as the flat parameter buffer)."""
-        d = self.last
-        assert "lstm" in d and "g1" in d["lstm"], "backward needs a forward(train=True)"
+    def backward(self, dout, gen=None):
+        """dout [B', O, F', T] fp32 -> flat parameter gradient (same layout as the flat parameter buffer).
+
+        Contract: ONE backward per train-mode forward, and it must be the latest one -- the saved activations live in
+        step-persistent workspaces that the next train-mode forward of this engine overwrites.  `gen` (the generation
+        number the forward returned in `last_train["gen"]`) makes a violation an error instead of a wrong gradient."""
+        d = self.last_train
+        if d is None or "lstm" not in d or "g1" not in d["lstm"]:
+            raise RuntimeError("backward needs a forward(train=True) first")
+        if gen is not None and gen != d["gen"]:
+            raise RuntimeError(
+                f"direction-net backward for forward #{gen}, but forward #{d['gen']} has since overwritten the saved "
+                "activations: this engine keeps ONE set of saved state (one backward per train-mode forward, no "
+                "gradient accumulation over micro-batches); run backward before the next forward")
+        if d.get("consumed"):
+            raise RuntimeError("direction-net backward called twice for one forward (retain_graph / double backward are "
+                               "not supported: the flat gradient buffer is overwritten, not accumulated)")
+        d["consumed"] = True
         s = H.stream()
         prec, dt, dev = self.prec, self.dt, self.dev
         B, T, Tv, Tp = d["B"], d["T"], d["Tv"], d["Tp"]
@@ -429,6 +451,9 @@ class FSNEngine:
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq)
+            if self.grad_range_hook is not None:
+                # the sub-band segment (LSTM + head: the tail of the flat buffer) is final once these GEMMs are done
+                self.grad_range_hook(G, self.fp.off["sb_model.sequence_model.weight_ih_l0"][0], G.numel())
         # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
         dpre_fb = ws("dpre_fb", (3, B, Tp, ldF), zero=True)
         Dsb = ws("Dsb", (B,), torch.float64)
@@ -540,6 +565,14 @@ class FSNEngine:
             H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
                    R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
             dXo, dXi = dXi, dXo
+            if i == 4 and self.grad_range_hook is not None:
+                # TCN blocks 7..4 of every branch are final once both queues have passed this point
+                def blocks_done():
+                    for br in BRANCHES:
+                        a = self.fp.off[f"fb_model{br}.sequence_model.4.conv1x1.weight"][0]
+                        b, shp = self.fp.off[f"fb_model{br}.sequence_model.7.sconv.bias"]
+                        self.grad_range_hook(G, a, b + int(np.prod(shp)))
+                on_side(blocks_done)
         if tn_ok:
             dXo = dXL[0]
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)

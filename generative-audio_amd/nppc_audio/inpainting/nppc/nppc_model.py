@@ -47,19 +47,18 @@ class NPPCModel(nn.Module):
         self._memo = None
 
     def _load_from_local(self):
-        """nppc_model.py:100-117: {'model_state_dict': UNet state dict}; the restorer stays in eval mode"""
-        print(f"Loading pretrained model from local path: {self.config.pretrained_restoration_model_path}")
+        """Restorer weights from a local checkpoint file (the reference's local branch, nppc_model.py:100-117):
+        the file holds {'model_state_dict': <UNet state dict>}, loaded strictly; the wrapped net is frozen in eval
+        mode.  Any failure (missing file, missing key, shape mismatch) surfaces as a RuntimeError naming the path."""
+        path = Path(self.config.pretrained_restoration_model_path).absolute()
+        unet = UNet(self.config.pretrained_restoration_model_configuration)
         try:
-            checkpoint_path = Path(self.config.pretrained_restoration_model_path).absolute()
-            checkpoint = torch.load(checkpoint_path, map_location="cpu")
-            base_net = UNet(self.config.pretrained_restoration_model_configuration)
-            base_net.load_state_dict(checkpoint['model_state_dict'])
-            base_net.to(self.device)
-            self.pretrained_restoration_model = RestorationWrapper(base_net)
-            self.pretrained_restoration_model.eval()
-            print("Successfully loaded pretrained model from local path")
-        except Exception as e:
-            raise RuntimeError(f"Failed to load model from local path: {str(e)}")
+            state = torch.load(path, map_location="cpu")["model_state_dict"]
+            unet.load_state_dict(state)
+        except Exception as err:
+            raise RuntimeError(f"could not load the restoration U-Net from {path}: {err}") from err
+        self.pretrained_restoration_model = RestorationWrapper(unet.to(self.device)).eval()
+        print(f"restoration U-Net loaded from {path}")
 
     def train(self, mode: bool = True):
         # nn.Module.train() would flip the frozen restorer into train mode; the reference never calls it on the

@@ -26,7 +26,8 @@ class _DirectionNetFn(torch.autograd.Function):
     def forward(ctx, net, n_maps_tensors, *tensors):
         maps = tensors[:n_maps_tensors]
         eng = net.engine()
-        out = eng.forward(list(maps), train=torch.is_grad_enabled() or True)
+        out = eng.forward(list(maps), train=True)
+        ctx.gen = eng.last_train["gen"]
         ctx.net = net
         ctx.n_maps_tensors = n_maps_tensors
         return out
@@ -34,7 +35,7 @@ class _DirectionNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.net.engine()
-        eng.backward(dout.contiguous().float())
+        eng.backward(dout.contiguous().float(), gen=ctx.gen)
         grads = [None] * ctx.n_maps_tensors
         if ctx.net.flat_grad_only:
             # the caller (NPPCAudioTrainer.train_step) consumes the flat gradient buffer directly: one all-reduce, one

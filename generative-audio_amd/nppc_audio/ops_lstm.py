@@ -65,9 +65,31 @@ def _n_cu():
     return N_CU
 
 
+def _flag_blocks():
+    return [t for k, t in _WS.items() if k[0][-1] == "coop_flags"]
+
+
 def coop_timeouts():
-    """Number of cooperative launches whose bounded spins gave up (0 on a healthy run); reads the device."""
-    return sum(int(t[-4].item()) for k, t in _WS.items() if k[0][-1] == "coop_flags")
+    """Bounded hand-off spins that gave up since the counters were last cleared (0 on a healthy run).  The counter word
+    of every flag block is STICKY: kernels only add to it and no launcher clears it (csrc/lstm_coop.hip), so a time-out
+    in ANY earlier launch is still visible here.  Reads the device (one small copy per flag block: call it where the
+    host synchronises anyway)."""
+    return sum(int(t[-4].item()) for t in _flag_blocks())
+
+
+def clear_coop_timeouts():
+    for t in _flag_blocks():
+        t[-4:].zero_()
+
+
+def check_coop_timeouts(where):
+    """raise if any cooperative LSTM hand-off timed out: the kernels carry on with wrong numbers after a time-out, so
+    everything computed since (gradients, Adam state) is suspect"""
+    n = coop_timeouts()
+    if n:
+        clear_coop_timeouts()
+        raise RuntimeError(f"{n} cooperative LSTM hand-off time-out(s) detected at {where}: a partner workgroup was not "
+                           "co-resident or stalled; results since the last check are invalid")
 
 
 def workspace(key, shape, dtype, device, zero=False):

@@ -24,7 +24,9 @@ import torch.optim as optim
 
 from . import _hip as H
 from . import ops
-from .data import AudioDataset, DataConfig, DataLoaderConfig
+from . import ops_lstm
+from .data import AudioDataset, DataConfig, DataLoaderConfig, DeviceMixLoader
+from .dp import FlatGradientReducer, mean_reduce_parameter_grads
 from .nppc_model import NPPCModel, NPPCModelConfig
 from .pc_ops import NPPCLoss, second_moment_weight
 
@@ -215,21 +217,26 @@ class NPPCAudioTrainer(nn.Module):
         print(f"Total sample pairs in dataset: {len(dataset)}")
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-        sampler = None
-        bs = config.data_loader_configuration.batch_size
+        lc = config.data_loader_configuration
+        bs = lc.batch_size
+        batch_sampler = None
         if self.world > 1:
             # contiguous equal shards of every global minibatch: rank r takes samples
             # [r*bs/W, (r+1)*bs/W) of each batch, so `i_global mod G == i_local mod G` for even local batches
             assert bs % self.world == 0, "global batch must divide evenly over the ranks"
-            sampler = ShardedBatchSampler(len(dataset), bs, self.world, self.rank, config.data_loader_configuration.shuffle)
-            self.dataloader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler,
-                                                          num_workers=config.data_loader_configuration.num_workers,
-                                                          pin_memory=config.data_loader_configuration.pin_memory)
+            batch_sampler = ShardedBatchSampler(len(dataset), bs, self.world, self.rank, lc.shuffle)
+        if isinstance(dataset, AudioDataset) and str(self.device).startswith("cuda"):
+            # wav-folder dataset on a HIP device: crops are cut on the host, the minibatch is mixed by ONE kernel launch
+            if batch_sampler is None:
+                base = (torch.utils.data.RandomSampler if lc.shuffle else torch.utils.data.SequentialSampler)(dataset)
+                batch_sampler = torch.utils.data.BatchSampler(base, bs, drop_last=False)
+            self.dataloader = DeviceMixLoader(dataset, batch_sampler, device=self.device, pin_memory=lc.pin_memory)
+        elif batch_sampler is not None:
+            self.dataloader = torch.utils.data.DataLoader(dataset, batch_sampler=batch_sampler, num_workers=lc.num_workers,
+                                                          pin_memory=lc.pin_memory)
         else:
-            self.dataloader = torch.utils.data.DataLoader(
-                dataset, batch_size=bs, shuffle=config.data_loader_configuration.shuffle,
-                num_workers=config.data_loader_configuration.num_workers,
-                pin_memory=config.data_loader_configuration.pin_memory)
+            self.dataloader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=lc.shuffle,
+                                                          num_workers=lc.num_workers, pin_memory=lc.pin_memory)
         self.step = 0
         # the frozen restorer never needs gradient buffers; the reference leaves requires_grad on and relies on
         # no_grad (nppc_model.py:94) -- same effect, and its parameters are still handed to the optimizer below
@@ -239,6 +246,7 @@ class NPPCAudioTrainer(nn.Module):
         else:
             self.optimizer = getattr(optim, okind)(self.nppc_model.parameters(), **config.optimizer_configuration.args)
         self._flat_adam = None
+        self._reducer = FlatGradientReducer()
 
     # ---------------------------------------------------------------------------------- reference API
     def base_step(self, batch):
@@ -262,27 +270,24 @@ class NPPCAudioTrainer(nn.Module):
         net = self.nppc_model.audio_pc_wrapper.net
         fast = isinstance(self.optimizer, HipAdam)
         net.flat_grad_only = fast
+        eng = net.engine()
+        # buckets of the flat gradient start their all-reduce from inside backward as soon as they are final (dp.py)
+        eng.grad_range_hook = self._reducer.range_ready if (fast and self.world > 1) else None
         try:
             reconst_err, objective, log = self.base_step(batch)
             self.optimizer.zero_grad()
             objective.backward()
         finally:
             net.flat_grad_only = False
-        eng = net.engine()
-        scale = 1.0 / self.world
+            eng.grad_range_hook = None
         if fast:
             gflat = eng.fp.grad
-            if self.world > 1:
-                torch.distributed.all_reduce(gflat)          # sum; the mean's 1/W is folded into Adam's grad scale
+            scale = self._reducer.finish(gflat)              # sum over ranks; the mean's 1/W goes into Adam's grad scale
             if self._flat_adam is None or self._flat_adam.eng is not eng:
                 self._flat_adam = FlatAdamStepper(self.optimizer, eng)
             self._flat_adam.step(gflat, scale)
         else:
-            if self.world > 1:
-                for p in net.parameters():
-                    if p.grad is not None:
-                        torch.distributed.all_reduce(p.grad)
-                        p.grad.mul_(scale)
+            mean_reduce_parameter_grads(net.parameters())
             self.optimizer.step()
         self.step += 1
         return reconst_err, objective, log
@@ -298,8 +303,12 @@ class NPPCAudioTrainer(nn.Module):
             else:
                 batch = batch.to(self.device)
             reconst_err, objective, log_dict = self.train_step(batch)
+            if it % log_every == 0 or it + 1 == len(loop_loader):
+                # host syncs only every log_every steps (the reference does three .item() per step, trainer.py:107-113);
+                # the same sync point checks the sticky hand-off time-out counter of the cooperative LSTM kernels, on
+                # every rank: after a time-out the kernels continue with wrong numbers
+                ops_lstm.check_coop_timeouts(f"step {self.step}")
             if self.rank == 0 and (it % log_every == 0 or it + 1 == len(loop_loader)):
-                # host syncs only every log_every steps (the reference does three .item() per step, trainer.py:107-113)
                 print(f'step {self.step}: Objective: {objective.item():.4f} | '
                       f'Second Moment MSE: {log_dict["second_moment_mse"].mean().item():.4f} | '
                       f'Reconstract Error: {reconst_err.mean().item():.4f}')
@@ -345,7 +354,7 @@ class ShardedBatchSampler(torch.utils.data.Sampler):
         self.epoch = 0
 
     def __len__(self):
-        return (self.n + self.gb - 1) // self.gb
+        return self.n // self.gb          # the ragged tail is dropped (__iter__), so every rank has equal work
 
     def __iter__(self):
         if self.shuffle:

@@ -104,8 +104,10 @@ int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, floa
 /* ---- sub-band stage: unfold + concat + laplace norm + drop_band + LSTM input layout, output head ------------
  * audio_zen/model/base_model.py:15-46, fullsubnet_plus.py:188-230, nppc_audio/networks.py:115-161,
  * sequence_model.py:118-123 (fc_output_layer) */
+/* work: caller-owned, 2*B 8-byte words (B fp64 partial sums + B arrival counters), zeroed ONCE by the caller; the kernel
+ * re-arms it, so the same workspace serves every later launch and launches on different workspaces may overlap */
 int nppc_subband_mean(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* mult,
-                      float* scale, int B, int F, int Tp, int Tv, int nfeat, void* stream);
+                      float* scale, double* work, int B, int F, int Tp, int Tv, int nfeat, void* stream);
 int nppc_subband_stage(int prec, const void* src, int ldS, const void* fb, int ldF, long strideFb, const float* scale,
                        void* x, int B, int F, int Tp, int Tv, int nb, int G, int KX, int ones_col, void* stream);
 int nppc_subband_stage_bwd(int prec, const void* dx, const void* x, const void* fb, const float* scale, double* D,
@@ -127,8 +129,12 @@ int nppc_lstm2_fwd(int prec, int train, int mtile, const void* x, const void* wp
                    const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2, long N, int Tn, int I,
                    int H, void* stream);
 /* Cooperative forward: G workgroups (CUs) share a tile of 16*mtile sequences and split the hidden units, each streaming
- * 1/G of the weights; h slices cross CUs through `xch` with bounded-spin epoch flags (`flags`, zeroed by the launcher;
- * the word after the last flag is set on a spin timeout).  Same tensor contract as nppc_lstm2_fwd. */
+ * 1/G of the weights; h slices cross CUs through `xch` with bounded-spin epoch flags.  `flags` (caller-owned, at least
+ * clusters*2*G + 4 words, zero-initialised ONCE by the caller) = the epoch words, which every launcher of this family
+ * zeroes itself, followed by the STICKY hand-off time-out counter flags[clusters*2*G]: a workgroup whose bounded spin
+ * gives up adds 1 to it and carries on with wrong numbers; no launcher ever clears it, so a host read at any later time
+ * sees a time-out of any earlier launch on this flag block.  The caller clears it (a 4-byte memset) after handling it.
+ * Same tensor contract as nppc_lstm2_fwd. */
 int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, int* mtile, int* clusters);
 int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
                         const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
@@ -200,9 +206,11 @@ int nppc_loss_bwd_coef_dev(const double* coefA, const double* coefE, const float
 int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                    double wd, int step, double gscale, void* stream);
 
-/* ---- on-device batch synthesis (dataset/audio_dataset.py:92-152: dBFS normalisation, SNR mix, clip guard) ------- */
-int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, float* noisy_out,
-                 float* clean_out, int B, int L, void* stream);
+/* ---- on-device batch synthesis (dataset/audio_dataset.py:92-152: dBFS normalisation, SNR mix, clip guard) -------
+ * target_item (nullable): per-clip normalisation level [B] in dBFS (the reference's target_dB_FS_floating_value > 0
+ * draws one per item, :94-101); null = target_dbfs for every clip */
+int nppc_mix_snr(const float* clean, const float* noise, const float* snr_db, float target_dbfs, const float* target_item,
+                 float* noisy_out, float* clean_out, int B, int L, void* stream);
 
 /* inpainting batch synthesis (dataset/audio_dataset_inpainting.py __getitem__ :291-313), one launch per batch:
  * _normalize_audio (:154-168, when do_norm), the gap mask of _create_random_mask (:170-181: zeros on

@@ -135,8 +135,23 @@ def run_config(name, c, out_dir):
         assert tuple(v.shape) == tuple(spec[k]), (k, v.shape, spec[k])
     model.load_state_dict(to_t(wts), strict=True)
 
-    out = {"noisy": noisy, "clean": clean}
+    lite = bool(c.get("lite"))
     meta = {"config": c, "n_tensors": len(spec), "n_elems": int(sum(np.prod(s) for s in spec.values()))}
+    if lite:
+        # long clips: the waveforms are regenerated by the tests (oracle/weights.synth_batch, checked by CRC) and maps
+        # larger than 64 K elements are stored on a strided (bin, frame) lattice; the per-sample loss terms, which
+        # depend on every element, stay complete
+        out = {}
+        meta["noisy_crc"], meta["clean_crc"] = crc(noisy), crc(clean)
+        meta["lattice"] = [5, 7]
+    else:
+        out = {"noisy": noisy, "clean": clean}
+
+    def keep(a):
+        a = np.asarray(a)
+        if lite and a.ndim >= 2 and a.size > 65536:
+            return np.ascontiguousarray(a[..., ::5, ::7])
+        return a
 
     # ---- intermediates via forward hooks -------------------------------------------------
     caps = {}
@@ -150,7 +165,7 @@ def run_config(name, c, out_dir):
     rest = model.pretrained_restoration_model
     pc = model.audio_pc_wrapper.net
     hs = []
-    for nm, net in (("rest", rest), ("pc", pc)):
+    for nm, net in (() if lite else (("rest", rest), ("pc", pc))):
         hs.append(net.channel_attention.register_forward_hook(hook(nm + ".att_mag", True)))
         hs.append(net.channel_attention_real.register_forward_hook(hook(nm + ".att_real", True)))
         hs.append(net.channel_attention_imag.register_forward_hook(hook(nm + ".att_imag", True)))
@@ -165,7 +180,7 @@ def run_config(name, c, out_dir):
     tnoisy = torch.from_numpy(noisy)
     tclean = torch.from_numpy(clean)
     mag, re, im = ref_utils.prepare_input_from_waveform(tnoisy, c["nfft"], c["hop"], c["nfft"], "cpu")
-    out["noisy_mag"], out["noisy_real"], out["noisy_imag"] = mag.numpy(), re.numpy(), im.numpy()
+    out["noisy_mag"], out["noisy_real"], out["noisy_imag"] = keep(mag.numpy()), keep(re.numpy()), keep(im.numpy())
 
     tr.step = 0
     reconst_err, objective, log = tr.base_step((tnoisy, tclean))
@@ -199,21 +214,22 @@ def run_config(name, c, out_dir):
 
     with torch.no_grad():
         pred_full = model.get_pred_crm(tnoisy)                     # compressed, not drop-banded
-        out["pred_crm_full"] = pred_full.numpy()
+        out["pred_crm_full"] = keep(pred_full.numpy())
         dec = decompress_cIRM(pred_full.permute(0, 2, 3, 1))
-        out["pred_crm_decompressed"] = dec.numpy()
+        if not lite:
+            out["pred_crm_decompressed"] = dec.numpy()
         emag, ere, eim = ref_utils.crm_to_stft_components(dec, re, im)
-        out["enh_mag"], out["enh_real"], out["enh_imag"] = emag.numpy(), ere.numpy(), eim.numpy()
+        out["enh_mag"], out["enh_real"], out["enh_imag"] = keep(emag.numpy()), keep(ere.numpy()), keep(eim.numpy())
         raw = model.audio_pc_wrapper.net(mag, re, im, emag.unsqueeze(1), ere.unsqueeze(1), eim.unsqueeze(1))
-        out["pc_raw"] = raw.numpy()
+        out["pc_raw"] = keep(raw.numpy())
         gt, pred = tr._get_true_and_pred_crm(tclean, model, tnoisy, c["G_pc"])
-        out["gt_crm"], out["pred_crm"] = gt.numpy(), pred.numpy()
+        assert np.array_equal(log["pred_crm"].numpy(), pred.numpy())
+        out["gt_crm"], out["pred_crm"] = keep(gt.numpy()), keep(pred.numpy())
 
     for k in ("w_mat", "err_norm", "err_proj_mag", "w_norms", "reconst_err", "second_moment_mse", "objective"):
-        out["log." + k] = log[k].numpy()
+        out["log." + k] = keep(log[k].numpy())
     out["log.err_proj_re"] = log["err_proj"].real.numpy()
     out["log.err_proj_im"] = log["err_proj"].imag.numpy()
-    assert np.array_equal(out["log.pred_crm"] if "log.pred_crm" in out else log["pred_crm"].numpy(), out["pred_crm"])
 
     objs = {}
     for st in (0, 250, 375, 500):
@@ -288,15 +304,16 @@ def run_config(name, c, out_dir):
                 out[f"adam2.{n}"] = small(params[n].detach().numpy())
 
     # ---- standalone pieces ---------------------------------------------------------------------
-    rng = np.random.Generator(np.random.PCG64(77))
-    xg = rng.standard_normal((3, 4, 2, 9, 11)).astype(np.float32)
-    xg[1, 2] = xg[1, 0] * 0.7 + 1e-3 * xg[1, 2]            # nearly collinear case
-    out["gs.in"] = xg
-    out["gs.out"] = gram_schmidt_to_crm(torch.from_numpy(xg)).numpy()
-    db_in = torch.arange(6 * 2 * 9 * 3, dtype=torch.float32).reshape(6, 2, 9, 3)
-    out["dropband.in"] = db_in.numpy()
-    for g in (2, 3):
-        out[f"dropband.out{g}"] = drop_band(db_in, g).numpy()
+    if not lite:
+        rng = np.random.Generator(np.random.PCG64(77))
+        xg = rng.standard_normal((3, 4, 2, 9, 11)).astype(np.float32)
+        xg[1, 2] = xg[1, 0] * 0.7 + 1e-3 * xg[1, 2]            # nearly collinear case
+        out["gs.in"] = xg
+        out["gs.out"] = gram_schmidt_to_crm(torch.from_numpy(xg)).numpy()
+        db_in = torch.arange(6 * 2 * 9 * 3, dtype=torch.float32).reshape(6, 2, 9, 3)
+        out["dropband.in"] = db_in.numpy()
+        for g in (2, 3):
+            out[f"dropband.out{g}"] = drop_band(db_in, g).numpy()
 
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
     with open(os.path.join(out_dir, name + ".json"), "w") as f:
@@ -313,6 +330,10 @@ CONFIGS = {
     "g1_c1": dict(F=257, nfft=512, hop=256, sbn=15, fbh=512, sbh=384, K=2, B=2, L=16000, G_rest=1, G_pc=1, seed=21),
     # reference training yaml shape at reduced batch/length: K=5, direction net G=2
     "g2_k5": dict(F=257, nfft=512, hop=256, sbn=15, fbh=512, sbh=384, K=5, B=4, L=8192, G_rest=1, G_pc=2, seed=31),
+    # BASELINE config 5's code paths at a size the reference finishes in minutes: 6 s clips (T' = 378 > 253), K = 8
+    # (16 head outputs), odd batch 3 with G_pc = 2 (384 direction-net sequences: the small-N cooperative plans)
+    "g3_long": dict(F=257, nfft=512, hop=256, sbn=15, fbh=512, sbh=384, K=8, B=3, L=96000, G_rest=1, G_pc=2, seed=41,
+                    lite=True),
 }
 
 

@@ -1,7 +1,8 @@
 """CPU, world_size 2 (gloo): the data-parallel recipe of NPPCAudioTrainer -- contiguous equal shards of the global
-minibatch, ONE sum all-reduce of the flat gradient, 1/W folded into the optimizer's gradient scale -- reproduces the
-single-process global-batch objective and gradients.  The arithmetic is the CPU oracle (the HIP model needs a GPU);
-what is under test is the sharding / collective / scaling logic that trainer.train_step uses."""
+minibatch (trainer.ShardedBatchSampler), the bucketed sum all-reduce of the flat gradient with the 1/W handed to the
+optimizer's gradient scale (dp.FlatGradientReducer: the SAME object train_step drives from the engine's range hooks) --
+reproduces the single-process global-batch objective and gradients.  The arithmetic is the CPU oracle (the HIP model
+needs a GPU).  Also: bench.py --gpus N starts its own ranks and propagates a failing rank's exit code."""
 import os
 import socket
 
@@ -41,8 +42,15 @@ def _worker(rank, world, port, out):
     noisy, clean = (torch.from_numpy(a) for a in W.synth_batch(CFG["B"], CFG["L"]))
     idx = next(iter(ShardedBatchSampler(CFG["B"], CFG["B"], world, rank, shuffle=False)))
     obj, g = _objective_and_flat_grad(noisy[idx], clean[idx], _weights())
-    dist.all_reduce(g)                                   # sum, as trainer.train_step does on the flat buffer
-    g *= 1.0 / world                                     # the 1/W that train_step folds into Adam's grad scale
+    # what NPPCAudioTrainer.train_step does: the engine reports final ranges from inside backward (here: the tail of
+    # the buffer first, then a middle range, like the sub-band segment and TCN blocks 7..4), `finish` covers the rest
+    from nppc_audio.dp import FlatGradientReducer
+    red = FlatGradientReducer()
+    assert red.world == world
+    n = g.numel()
+    red.range_ready(g, n - n // 5, n)
+    red.range_ready(g, n // 3, n // 2)
+    g *= red.finish(g)                                   # the returned 1/W is what train_step hands to Adam's grad scale
     o = torch.tensor([obj], dtype=torch.float64)
     dist.all_reduce(o)
     if rank == 0:
@@ -68,3 +76,31 @@ def test_two_rank_dp_equals_global_batch(tmp_path):
     assert float((got["g"] - g).abs().max()) < 2e-3 * float(g.abs().max())
     cos = float((got["g"].double() @ g.double()) / (got["g"].double().norm() * g.double().norm()))
     assert cos > 0.99999
+
+
+def _bench(*args):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no external launcher: the ranks come up (gloo rehearsal of the exchange on CPU),
+    rank 0 prints ONE JSON line, exit code 0"""
+    import json
+    r = _bench("--gpus", "2", "--dp-selftest")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"dp_selftest": True, "n_gpus": 2, "scale": 0.5}
+
+
+def test_bench_exits_nonzero_when_a_rank_fails():
+    r = _bench("--gpus", "2", "--dp-selftest", "--dp-selftest-fail-rank", "1")
+    assert r.returncode != 0

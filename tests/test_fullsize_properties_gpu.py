@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 B, L, K = 32, 64000, 5
 
 
-def _model(precision, tmp):
+def _model(precision, tmp, n_dirs=K, g_pc=2):
     from nppc_audio.fullsubnet import FullSubNet_Plus, FullSubNetPlusConfig
     from nppc_audio.nppc_model import NPPCModel, NPPCModelConfig
     torch.manual_seed(0)
@@ -22,8 +22,8 @@ def _model(precision, tmp):
     cfg = NPPCModelConfig(
         pretrained_restoration_model_configuration=dict(num_groups_in_drop_band=1, precision=precision),
         pretrained_restoration_model_path=ck,
-        audio_pc_wrapper_configuration=dict(multi_direction_configuration=dict(num_groups_in_drop_band=2, n_directions=K,
-                                                                               precision=precision)),
+        audio_pc_wrapper_configuration=dict(multi_direction_configuration=dict(num_groups_in_drop_band=g_pc,
+                                                                               n_directions=n_dirs, precision=precision)),
         stft_configuration=dict(nfft=512, hop_length=256, win_length=512), device="cuda")
     return NPPCModel(cfg)
 
@@ -99,11 +99,60 @@ def test_train_step_properties_full_size(batch, tmp_path):
     assert np.abs(out["bf16"][2] - out["fp32"][2]).max() / np.abs(out["fp32"][2]).max() < 8e-2
 
 
-def test_inpainting_step_properties_full_size(tmp_path):
+@pytest.mark.parametrize("g_pc", [2, 1])
+def test_train_step_properties_config5(g_pc, tmp_path):
+    """BASELINE config 5 at full size: 8 x 30 s clips, K = 8 (T' = 1878; 2056 restorer sequences, 1024 / 2056 direction-net
+    sequences: the small-N cooperative plans, 16 head outputs).  Same size-independent properties as the C2 test."""
+    from nppc_audio import ops_lstm
+    from nppc_audio.data import SyntheticNoisySpeech
+    from nppc_audio.trainer import nppc_base_step
+    B5, L5, K5 = 8, 480000, 8
+    ds = SyntheticNoisySpeech(B5, L5)
+    clips = [ds[i] for i in range(B5)]
+    noisy, clean = torch.stack([c[0] for c in clips]).cuda(), torch.stack([c[1] for c in clips]).cuda()
+    Fo = 128 if g_pc == 2 else 257
+    out = {}
+    for precision in (("bf16", "fp32") if g_pc == 2 else ("bf16",)):
+        model = _model(precision, str(tmp_path), n_dirs=K5, g_pc=g_pc)
+        rec, obj, log = nppc_base_step(model, (noisy, clean), 500, 500, 1.0)
+        model.zero_grad()
+        obj.backward()
+        torch.cuda.synchronize()
+        assert ops_lstm.coop_timeouts() == 0                         # sticky: covers every launch so far
+        w = log["w_mat"].double()
+        assert tuple(w.shape) == (B5, K5, 2, Fo, 1876)
+        wc = torch.complex(w[:, :, 0], w[:, :, 1]).flatten(2)
+        gram = torch.einsum("bkn,bjn->bkj", wc.conj(), wc)
+        diag = torch.diagonal(gram, dim1=1, dim2=2).real
+        assert float(gram[:, 0, 1].real.abs().max() / diag.max()) < (5e-3 if precision == "bf16" else 1e-4)
+        r = log["reconst_err"]
+        assert torch.isfinite(obj) and float(r.min()) > -1e-4 and float(r.max()) < 1 + 1e-4
+        assert float(log["second_moment_mse"].min()) >= 0.0
+        g = model.audio_pc_wrapper.net.engine().fp.grad
+        assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+        _, obj2, _ = nppc_base_step(model, (noisy, clean), 500, 500, 1.0)          # determinism
+        assert abs(float(obj2) - float(obj)) < 1e-5
+        halves = [nppc_base_step(model, (noisy[s], clean[s]), 500, 500, 1.0)[1] for s in (slice(0, 4), slice(4, 8))]
+        assert abs(0.5 * (float(halves[0]) + float(halves[1])) - float(obj)) < (2e-3 if precision == "bf16" else 2e-5)
+        torch.cuda.synchronize()
+        assert ops_lstm.coop_timeouts() == 0
+        out[precision] = (float(obj), log["reconst_err"].float().cpu().numpy(), log["pred_crm"].float().cpu().numpy())
+        del model
+        torch.cuda.empty_cache()
+    if "fp32" in out:
+        assert abs(out["bf16"][0] - out["fp32"][0]) < 3e-2
+        assert np.abs(out["bf16"][1] - out["fp32"][1]).max() < 8e-2
+        assert np.abs(out["bf16"][2] - out["fp32"][2]).max() / np.abs(out["fp32"][2]).max() < 8e-2
+
+
+@pytest.mark.parametrize("T", [500, 501])
+def test_inpainting_step_properties_full_size(T, tmp_path):
+    """C3 at full size.  T = 500 is what torch.stft(center=True) gives the reference for 4 s clips with nfft 255 / hop 128
+    (1 + (64000 + 2*127 - 255) // 128); SURVEY.md section 8 quotes 501, so the odd frame count is exercised too."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import bench_inpainting as bi
-    F, T = 128, 500
+    F = 128
     tr = bi.build("bf16", B, F, T)
     masked, mask, clean = bi.synth(B, F, T, "cuda")
     tr.step = 500

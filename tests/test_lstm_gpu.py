@@ -302,3 +302,127 @@ def test_fused_head_backward_equals_separate_kernels(N, Tn, O, Fo, la):
         x, y = x.float(), y.float()
         assert bool(torch.isfinite(y).all()), name
         assert float((x - y).abs().max()) < 2e-2 * float(x.abs().max()) + 1e-6, name     # dh2 rounded to bf16 on one side only
+
+
+def _production_setup(N, Tn, seed):
+    """same weights and inputs packed for the bf16 production kernels and for the fp32 single-workgroup kernels (the
+    fp32 kernels are the ones test_lstm_fwd_f32_matches_oracle / test_lstm_bwd_matches_autograd pin to the oracle)"""
+    from nppc_audio.ops_lstm import PackedLSTM, PackedLSTMBwd
+    I, Hd = 34, 384
+    P = _weights(I, Hd, seed)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")
+    wn = ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(Tn, N, I, generator=g)
+    out = {}
+    for prec in (0, 1):
+        pk = PackedLSTM(I, Hd, prec, dev).pack(*[P[pre + n].to(dev) for n in names])
+        pb = PackedLSTMBwd(I, Hd, prec, dev).pack(*[P[pre + n].to(dev) for n in wn])
+        xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16 if prec == 0 else torch.float32, device=dev)
+        xt[:, :, :I] = x.to(dev)
+        out[prec] = (pk, pb, xt)
+    return out, g
+
+
+def test_production_restorer_forward_full_width_against_fp32_kernel():
+    """BASELINE C2's restorer launch as the plan really makes it -- N = 8224 sequences, CU pairs with 80-row tiles, the
+    XCD-aware pair placement with the grid rounded to a multiple of 8 and its spare workgroups, the 2-output head fused --
+    against the product's own oracle-pinned fp32 single-workgroup kernel, 32 steps."""
+    import ctypes
+    from nppc_audio import _hip as H
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import lstm2_forward
+    N, Tn, O, Fo, la, Hd = 8224, 32, 2, 257, 2, 384
+    setup, g = _production_setup(N, Tn, 11)
+    G, mt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    H.call("nppc_lstm2_coop_plan", 0, 0, N, Hd, ops_lstm._n_cu(), ctypes.byref(G), ctypes.byref(mt), ctypes.byref(ncl))
+    assert G.value == 2 and ncl.value * 2 > 200, (G.value, mt.value, ncl.value)     # the wide pair plan, most of the chip
+    dev = torch.device("cuda")
+    wh = (torch.randn(O, Hd, generator=g) * 0.1)
+    bias = torch.randn(O, generator=g).to(dev)
+    s = H.stream()
+    pk32, _, x32 = setup[1]
+    ref = lstm2_forward(x32, pk32, False, 1)
+    wh32 = torch.zeros(16, Hd, device=dev)
+    wh32[:O] = wh.to(dev)
+    want = torch.empty(N // Fo, O, Fo, Tn - la, device=dev)
+    H.call("nppc_sb_head", 1, ref["h2"], wh32, bias, want, N, Tn, la, Hd, O, Fo, s)
+    pk16, _, x16 = setup[0]
+    fused = lstm2_forward(x16, pk16, False, None, head=(wh32.to(torch.bfloat16), O))
+    assert "head_partial" in fused
+    got = torch.full_like(want, float("nan"))
+    H.call("nppc_sb_head_finalize", fused["head_partial"], 2, bias, got, N, Tn, la, O, Fo, s)
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert bool(torch.isfinite(got).all())
+    # bf16 operands vs exact fp32: the forward tolerance of test_lstm_fwd_bf16_matches_oracle, on the head outputs
+    # (|Wh| ~ 0.1 x 384 units of |h| <= 1: the same order as h itself)
+    assert float((got - want).abs().max()) < 3e-2 * max(1.0, float(want.abs().max()))
+
+
+def test_production_direction_net_forward_backward_full_width_against_fp32_kernels():
+    """BASELINE C2's direction-net launches as planned -- N = 4096, training forward with saved state and the fused
+    10-output head, K-split cooperative backward with the head backward fused -- against the fp32 single-workgroup
+    forward + backward kernels, 32 steps: LSTM outputs, dx and both gate-gradient tensors."""
+    from nppc_audio import _hip as H
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import bwd_head_fusable, lstm2_backward, lstm2_forward
+    N, Tn, O, Fo, la, Hd = 4096, 32, 10, 128, 2, 384
+    setup, g = _production_setup(N, Tn, 12)
+    dev = torch.device("cuda")
+    s = H.stream()
+    wh = torch.randn(O, Hd, generator=g) * 0.2
+    dout = torch.randn(N // Fo, O, Fo, Tn - la, generator=g).to(dev)
+    # fp32 reference path
+    pk32, pb32, x32 = setup[1]
+    sv32 = lstm2_forward(x32, pk32, True, 1)
+    whT32 = torch.zeros(Hd, 32, device=dev)
+    whT32[:, :O] = wh.t().to(dev)
+    dh2 = torch.empty(Tn, N, Hd, device=dev)
+    dW, db = torch.zeros(O, Hd, device=dev), torch.zeros(O, device=dev)
+    H.call("nppc_sb_head_bwd", 1, dout, whT32, sv32["h2"], dh2, dW, db, N, Tn, la, Hd, O, Fo, s)
+    ref = [t.float().clone() for t in lstm2_backward(sv32, dh2, pb32, pk32.kx, coop=False)]
+    h2_ref = sv32["h2"].clone()
+    # production path
+    pk16, pb16, x16 = setup[0]
+    wh16 = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev)
+    wh16[:O] = wh.to(dev)
+    sv16 = lstm2_forward(x16, pk16, True, None, head=(wh16, O))
+    assert "head_partial" in sv16 and bwd_head_fusable(N, pb16)
+    dyt = torch.empty(Tn, N, 16, dtype=torch.bfloat16, device=dev)
+    H.call("nppc_head_dy_gather", dout, dyt, N, Tn, la, O, Fo, s)
+    got = [t.float() for t in lstm2_backward(sv16, None, pb16, pk16.kx, head=(dyt, whT32.to(torch.bfloat16)))]
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert float((sv16["h2"].float() - h2_ref).abs().max()) < 3e-2
+    R_ = Tn * N
+    for name, a, b in zip(("dx", "dg1", "dg2"), got, ref):
+        a, b = (a[:R_], b[:R_]) if a.dim() == 2 else (a, b)
+        assert bool(torch.isfinite(a).all()), name
+        d = float((a - b).abs().max()) / float(b.abs().max())
+        assert d < 4e-2, (name, d)           # the backward tolerance of test_lstm_bwd_matches_autograd (bf16)
+
+
+def test_handoff_timeout_counter_is_sticky():
+    """a recorded hand-off time-out must survive later launches on the same flag block (the launchers zero the epoch
+    words only) until the host clears it; check_coop_timeouts raises and clears"""
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import lstm2_forward
+    setup, _ = _production_setup(96, 5, 13)
+    pk16, _, x16 = setup[0]
+    lstm2_forward(x16, pk16, False, (2, 2))
+    torch.cuda.synchronize()
+    ops_lstm.clear_coop_timeouts()
+    assert ops_lstm.coop_timeouts() == 0
+    blocks = ops_lstm._flag_blocks()
+    assert blocks
+    blocks[-1][-4] = 7                                   # as if 7 bounded spins had given up in an earlier launch
+    for _ in range(3):
+        lstm2_forward(x16, pk16, False, (2, 2))          # same workspace key -> same flag block, epoch words re-zeroed
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 7
+    with pytest.raises(RuntimeError, match="hand-off time-out"):
+        ops_lstm.check_coop_timeouts("test")
+    assert ops_lstm.coop_timeouts() == 0

@@ -18,15 +18,38 @@ def _bench():
     return m
 
 
-def test_pmc_traffic_lookup_matches_the_committed_summary():
+def test_pmc_traffic_lookup_is_stamped_with_the_profiled_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed rocprofv3 counter passes; it is reported only while the kernel sources of
+    the running tree are the ones that were profiled (hash in the stamp file), and only for the profiled workload"""
+    import json
     b = _bench()
-    for name in ("lstm2_bwd_coop_ksplit[N=4096,T'=253,mtile=2]", "lstm2_fwd_coop_g2[N=8224,T'=253,mtile=5]",
-                 "lstm2_fwd_coop_g2[N=4096,T'=253,mtile=2]"):
-        nbytes, note = b.pmc_traffic(name)
-        assert nbytes is not None and 1e9 < nbytes < 1e11, (name, nbytes, note)
-        assert "profiles/" in note
-    nbytes, note = b.pmc_traffic("lstm2_fwd_coop_g4[N=1024,T'=1878,mtile=4]")          # another configuration: honest null
-    assert nbytes is None and note
+    csvp, stamp = tmp_path / "t.csv", tmp_path / "s.json"
+    csvp.write_text("kernel,launches,FETCH_SIZE_sum_KB,WRITE_SIZE_sum_KB,fetch_MB_per_launch_x2_corrected,write_MB_per_launch\n"
+                    '"void lstm2_coop_bwd2_kernel<...>(Args)",13,1,1,1000.0,500.0\n'
+                    '"void lstm2_coop_fwd_kernel<bf16, 2, 5, 64, false, true>(CoopArgs)",13,1,1,300.0,20.5\n')
+    monkeypatch.setattr(b, "PMC_CSV", str(csvp))
+    monkeypatch.setattr(b, "PMC_STAMP", str(stamp))
+    stamp.write_text(json.dumps({"kernel_source_hash": b.kernel_source_hash(), "git_head": "abc1234"}))
+    nbytes, note = b.pmc_traffic("lstm2_coop_bwd2_kernel", "C2")
+    assert nbytes == 1500.0 * 1048576 and "abc1234" in note
+    nbytes, _ = b.pmc_traffic(b.ROCPROF_NAME["lstm2_fwd_coop_g2[N=8224"], "C2")
+    assert nbytes == 320.5 * 1048576
+    assert b.pmc_traffic("lstm2_coop_bwd2_kernel", "C5")[0] is None                  # another workload: honest null
+    assert b.pmc_traffic("no_such_kernel", "C2")[0] is None
+    stamp.write_text(json.dumps({"kernel_source_hash": "0" * 16, "git_head": "abc1234"}))
+    nbytes, note = b.pmc_traffic("lstm2_coop_bwd2_kernel", "C2")                      # kernels changed since the pass
+    assert nbytes is None and "stale" in note
+
+
+def test_algorithmic_work_matches_the_survey_figures():
+    """bench.py's FLOP / byte formulas against SURVEY.md section 8(d)'s numbers for BASELINE C2 and C5"""
+    b = _bench()
+    assert abs(b.step_flops(32, 251, 5) / 1.968e13 - 1) < 5e-3
+    assert abs(b.step_flops(8, 1876, 8) / 3.65e13 - 1) < 5e-3
+    fam = b.hbm_family_bytes(32, 64000, 251, 5, 15_198_636, 2)
+    assert abs(fam["stft"][0] / 57.7e6 - 1) < 0.02 and abs(fam["cirm_build_compress"][0] / 49.5e6 - 1) < 0.01
+    assert abs(fam["cirm_decompress_apply"][0] / 57.8e6 - 1) < 0.01 and abs(fam["subband_staging_fwd"][0] / 66.6e6 - 1) < 0.01
+    assert abs(fam["gs_and_loss"][0] / 230e6 - 1) < 0.02 and abs(fam["adam"][0] / 426e6 - 1) < 0.01
 
 
 def test_summarize_pmc_on_a_synthetic_counter_file(tmp_path):

@@ -10,20 +10,29 @@ import torch
 from oracle import nppc_ref as R
 from oracle import weights as W
 
+from golden_util import lat, load, rel, waves
+
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load(name):
-    z = np.load(os.path.join(GOLD, name + ".npz"))
-    meta = json.load(open(os.path.join(GOLD, name + ".json")))
-    return z, meta
+def ill_conditioned(n):
+    """parameters of the real/imag full-band branches: offline_laplace_norm divides their signed input maps by
+    mean + 1e-5 ~ 1e-5 and GroupNorm makes the branch scale-invariant, so their true weight gradients are small
+    differences of large terms -- fp32 gradients of these tensors are noise-limited in the reference too"""
+    return "_real." in n or "_imag." in n
 
 
-def rel(a, b):
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+def check_against_reference_fp32_gradients(z, meta, got, tag="g500"):
+    """the fixtures hold slices (first 4096 elements) of 24 gradient tensors computed by the REFERENCE in fp32.
+    Tolerance, relative to the tensor's max |grad|: 1e-2 for the well-conditioned tensors; 0.3 for the real/imag
+    branches = two fp32 evaluations that are each up to 1.4e-1 from the fp64 truth."""
+    worst = {}
+    for n, (amax, l2) in meta[tag + ".grad_absmax_l2"].items():
+        g = got[n].grad.detach().float().cpu().numpy().reshape(-1)[:4096]
+        worst[n] = float(np.abs(g - z[f"{tag}.grad.{n}"]).max() / (amax + 1e-30))
+    bad = {n: r for n, r in worst.items() if r > (0.3 if ill_conditioned(n) else 1e-2)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])
+    return worst
 
 
 def build_model(c, precision, tmp_path):
@@ -45,6 +54,9 @@ def build_model(c, precision, tmp_path):
     return model, wts
 
 
+BF16_GRAD_TOL = 0.15
+
+
 @pytest.mark.parametrize("name,precision", [("g0_tiny", "fp32"), ("g1_c1", "fp32"), ("g2_k5", "fp32"),
                                             ("g2_k5", "bf16"), ("g0_tiny_g1", "fp32")])
 def test_train_step_matches_oracle(name, precision, tmp_path):
@@ -53,7 +65,8 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
     c = meta["config"]
     fp32 = precision == "fp32"
     model, wts = build_model(c, precision, str(tmp_path))
-    noisy, clean = torch.from_numpy(z["noisy"]).cuda(), torch.from_numpy(z["clean"]).cuda()
+    wn, wc = waves(z, meta)
+    noisy, clean = torch.from_numpy(wn).cuda(), torch.from_numpy(wc).cuda()
     step = 500
     reconst, obj, log = nppc_base_step(model, (noisy, clean), step, 500, 1.0)
     model.zero_grad()
@@ -72,6 +85,11 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
     # these fixtures: offline_laplace_norm divides the signed maps by mean+1e-5 ~ 1e-5, and GroupNorm makes the
     # branch scale-invariant, so the true weight gradients are a small difference of large terms).
     # The oracle at fp32 is pinned to the reference goldens in tests/test_oracle_golden.py.
+    if fp32:
+        # ... and, first, against the REFERENCE's own fp32 gradients (fixture slices) at the reference's noise floor
+        w = check_against_reference_fp32_gradients(z, meta, dict(model.named_parameters()))
+        print(name, "vs reference fp32 gradients, worst:", sorted(((n.replace("audio_pc_wrapper.net.", ""), f"{r:.1e}")
+                                                                     for n, r in w.items()), key=lambda kv: -float(kv[1]))[:5])
     P = {k: v.double() for k, v in wts.items()}
     for k, v in P.items():
         if k.startswith("audio_pc_wrapper"):
@@ -107,20 +125,66 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
         #        thread count: ReLU/PReLU kinks flip under the ~1e-5 relative noise of the laplace-norm scale);
         #   and, as the guard that matters for training, direction and norm of the full gradient vector.
         def tol_of(n):
-            return 0.25 if ("_real." in n or "_imag." in n) else 1e-2
+            return 0.25 if ill_conditioned(n) else 1e-2
         bad = {n: r for n, r in worst.items() if r > tol_of(n)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
         assert cos > 0.99999 and abs(np.sqrt(nn_g / nn_r) - 1) < 1e-4
     else:
-        # bf16 operands: the well-conditioned tensors (sub-band LSTM + head, magnitude branch) individually, the
-        # ill-conditioned real/imag branches through the direction and norm of the whole gradient
-        well = [n for n in names if ".sb_model." in n]
-        bad = {n: worst[n] for n in well if worst[n] > 0.15}
+        # bf16 operands (tolerance table: DESIGN.md section 2): EVERY well-conditioned tensor individually -- sub-band
+        # LSTM + head, magnitude-branch attention and TCN -- at BF16_GRAD_TOL of its max |grad|; the ill-conditioned
+        # real/imag branches (noise-limited even in the reference's fp32) through direction and norm of the whole gradient
+        well = [n for n in names if not ill_conditioned(n)]
+        assert len(well) > 100
+        fam = {}
+        for n in well:
+            k = ("sb_model" if ".sb_model." in n else "attention" if "channel_attention" in n else
+                 "tcn." + n.rsplit(".", 2)[-2] if ".sequence_model." in n else "fb_fc")
+            fam[k] = max(fam.get(k, 0.0), worst[n])
+        print(name, "bf16 worst error / max|grad| per well-conditioned family:", {k: f"{v:.2e}" for k, v in sorted(fam.items())})
+        bad = {n: worst[n] for n in well if worst[n] > BF16_GRAD_TOL}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
-        assert cos > 0.98 and abs(np.sqrt(nn_g / nn_r) - 1) < 0.1
+        assert cos > 0.99 and abs(np.sqrt(nn_g / nn_r) - 1) < 0.05
     assert abs(np.sqrt(nn_g) - meta["g500.grad_total_l2"]) < (2e-3 if fp32 else 1e-1) * meta["g500.grad_total_l2"]
     # the frozen restorer receives no gradient (trainer.py:66-69 hands its parameters to Adam anyway)
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("pretrained_restoration_model"))
+
+
+def test_long_clip_reference_golden(tmp_path):
+    """g3_long: 3 x 6 s clips, K = 8, G_pc = 2 (T' = 378, 16 head outputs, 771 / 384 sequences: BASELINE config 5's code
+    paths -- the small-N cooperative plans, O = 16 through the fused head) against outputs of the REFERENCE, fp32 mode at
+    the tolerances of the short fixtures.  Maps are compared on the fixture's strided lattice, the per-sample loss terms
+    (sums over every element) in full, gradients against the reference's own fp32 gradients."""
+    from nppc_audio import ops_lstm
+    from nppc_audio.trainer import nppc_base_step
+    z, meta = load("g3_long")
+    c = meta["config"]
+    model, wts = build_model(c, "fp32", str(tmp_path))
+    wn, wc = waves(z, meta)
+    noisy, clean = torch.from_numpy(wn).cuda(), torch.from_numpy(wc).cuda()
+    for step in (0, 500):
+        reconst, obj, log = nppc_base_step(model, (noisy, clean), step, 500, 1.0)
+        assert abs(float(obj) - meta["objective_at_step"][str(step)]) < 2e-5
+    model.zero_grad()
+    obj.backward()
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert tuple(log["w_mat"].shape) == (3, 8, 2, 128, 376)
+    assert rel(lat(log["pred_crm"].cpu().numpy(), meta), z["pred_crm"]) < 3e-4
+    assert rel(lat(log["w_mat"].cpu().numpy(), meta), z["log.w_mat"]) < 5e-4
+    for k in ("err_norm", "err_proj_mag", "w_norms", "reconst_err", "second_moment_mse"):
+        assert rel(log[k].cpu().numpy(), z["log." + k]) < 5e-4, k
+    check_against_reference_fp32_gradients(z, meta, dict(model.named_parameters()))
+    tot = np.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in model.parameters() if p.grad is not None))
+    assert abs(tot - meta["g500.grad_total_l2"]) < 2e-3 * meta["g500.grad_total_l2"]
+    # the bf16 production mode on the same clips: same plans at bf16 (cooperative kernels), looser stated tolerance
+    model16, _ = build_model(c, "bf16", str(tmp_path))
+    _, obj16, log16 = nppc_base_step(model16, (noisy, clean), 500, 500, 1.0)
+    model16.zero_grad()
+    obj16.backward()
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert abs(float(obj16) - meta["objective_at_step"]["500"]) < 2e-2
+    assert rel(lat(log16["pred_crm"].cpu().numpy(), meta), z["pred_crm"]) < 6e-2
 
 
 class _Mem(torch.utils.data.Dataset):
@@ -134,7 +198,7 @@ class _Mem(torch.utils.data.Dataset):
         return self.noisy[i], self.clean[i]
 
 
-@pytest.mark.parametrize("name,opt", [("g0_tiny", "Adam"), ("g2_k5", "Adam"), ("g0_tiny", "AdamW")])
+@pytest.mark.parametrize("name,opt", [("g0_tiny", "Adam"), ("g2_k5", "Adam"), ("g0_tiny", "AdamW"), ("g3_long", "Adam")])
 def test_two_optimizer_steps_through_the_trainer(name, opt, tmp_path):
     """NPPCAudioTrainer.train_step x 2 at steps 500, 501 against the reference's weights after one and two
     Adam steps (goldens adam1.*, adam2.*).  'Adam' takes the flat-buffer HIP optimizer, 'AdamW' (weight_decay 0:
@@ -149,7 +213,7 @@ def test_two_optimizer_steps_through_the_trainer(name, opt, tmp_path):
         data_loader_configuration=dict(batch_size=c["B"], num_workers=0, pin_memory=False, shuffle=False),
         optimizer_configuration=dict(type=opt, args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
         device="cuda")
-    noisy, clean = torch.from_numpy(z["noisy"]), torch.from_numpy(z["clean"])
+    noisy, clean = (torch.from_numpy(a) for a in waves(z, meta))
     tr = NPPCAudioTrainer(cfg, dataset=_Mem(noisy, clean))
     tr.nppc_model.load_state_dict(wts, strict=True)
     tr.nppc_model.to("cuda")

@@ -101,7 +101,7 @@ def cpu_baseline(F, T):
             "sample": f"1 train step, B={B} x 4 s (F={F}, T={T}), K={K_DIRS}, fp32, reference-shaped (2x restorer), {dt:.1f} s"}
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from nppc_audio import unet_engine
     L = int(a.seconds * 16000)
     F, T = NFFT // 2 + 1, 1 + (L + 2 * (NFFT // 2) - NFFT) // HOP
