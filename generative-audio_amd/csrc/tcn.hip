@@ -12,7 +12,11 @@
 
 namespace {
 
-enum { EPI_PLAIN = 0, EPI_PRELU_STATS = 1, EPI_RESIDUAL = 2, EPI_RELU = 3, EPI_PLAIN_F32 = 4, EPI_MASK_POS = 5 };
+enum { EPI_PLAIN = 0, EPI_PRELU_STATS = 1, EPI_RESIDUAL = 2, EPI_RELU = 3, EPI_PLAIN_F32 = 4, EPI_MASK_POS = 5, EPI_RESIDUAL_GN = 6 };
+// EPI_RESIDUAL_GN: the GroupNorm in front of the product is folded into it.  With a = (y - mean_b) * rstd_b * gamma + beta,
+//   a W^T = rstd_b * (y Wg^T) - mean_b * rstd_b * v + u,   Wg[n][k] = gamma[k] W[n][k],  v[n] = sum_k Wg[n][k],  u[n] = sum_k beta[k] W[n][k] + bias[n]
+// so the GEMM reads the un-normalised y (B operand = Wg, `bias` = u, `gnv` = v, `stats` = the per-sample (sum, sumsq) of y)
+// and the normalised activation is never written (nppc_tcn_pack_sconv builds Wg, u, v).
 
 struct GemmArgs {
   const void* A; long lda; long strideA;   // [R][lda]   (strides in elements, per batch z)
@@ -27,6 +31,8 @@ struct GemmArgs {
   int Nv;                                  // columns >= Nv are padding: forced to zero
   int relu_in;                             // apply ReLU to A on load (TCN trailing nn.ReLU before the Linear)
   int ksplit;                              // >1: blockIdx.z = batch*ksplit + s; slice s covers K elements [s*K, (s+1)*K)
+  const float* gnv; long strideGnv;        // EPI_RESIDUAL_GN: v[N]; `stats` then holds the GroupNorm (sum, sumsq) per sample
+  double gcnt; float geps;                 // ... elements per sample, epsilon
 };
 
 template <typename T> __device__ __forceinline__ typename Frag<T>::type relu_frag(typename Frag<T>::type f);
@@ -105,22 +111,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   const float* bias = g.bias ? g.bias + (size_t)z * g.strideBias : nullptr;
   float slope = 0.f;
   if (EPI == EPI_PRELU_STATS) slope = g.slope[(size_t)z * g.strideSlope];
+  float gn_rstd = 1.f, gn_mr = 0.f;        // EPI_RESIDUAL_GN: one sample per 128-row tile (Tp % 128 == 0)
+  const float* gnv = nullptr;
+  if (EPI == EPI_RESIDUAL_GN) {
+    const double* st = g.stats + (size_t)z * g.strideStats + (size_t)((blockIdx.x * 128) / g.Tp) * 2;
+    const double m = st[0] / g.gcnt, var = st[1] / g.gcnt - m * m;
+    gn_rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)g.geps));
+    gn_mr = (float)m * gn_rstd;
+    gnv = g.gnv + (size_t)z * g.strideGnv;
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int col = c0 + 16 * ni + n;
     const bool cvalid = col < g.Nv;
-    const float bv = (bias && cvalid) ? bias[col] : 0.f;
+    float bv = (bias && cvalid) ? bias[col] : 0.f;
+    if (EPI == EPI_RESIDUAL_GN && cvalid) bv -= gn_mr * gnv[col];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = r0 + 16 * mi + 4 * q + j;
         const bool valid = cvalid && (row % g.Tp) < g.Tv;
-        float v = acc[mi][ni][j] + bv;
+        float v = (EPI == EPI_RESIDUAL_GN ? gn_rstd * acc[mi][ni][j] : acc[mi][ni][j]) + bv;
         if (EPI == EPI_PRELU_STATS) v = v > 0.f ? v : slope * v;
         if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-        if (EPI == EPI_RESIDUAL) {
+        if (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_GN) {
           const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
           v += to_f32<T>(res[(size_t)row * g.ldres + col]);
         }
@@ -251,22 +267,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
   const float* bias = g.bias ? g.bias + (size_t)z * g.strideBias : nullptr;
   float slope = 0.f;
   if (EPI == EPI_PRELU_STATS) slope = g.slope[(size_t)z * g.strideSlope];
+  float gn_rstd = 1.f, gn_mr = 0.f;        // EPI_RESIDUAL_GN: one sample per 128-row tile (Tp % 128 == 0)
+  const float* gnv = nullptr;
+  if (EPI == EPI_RESIDUAL_GN) {
+    const double* st = g.stats + (size_t)z * g.strideStats + (size_t)(m0 / g.Tp) * 2;
+    const double m = st[0] / g.gcnt, var = st[1] / g.gcnt - m * m;
+    gn_rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)g.geps));
+    gn_mr = (float)m * gn_rstd;
+    gnv = g.gnv + (size_t)z * g.strideGnv;
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int col = n0 + wn * (BN / 2) + 16 * j + n;
     const bool cvalid = col < g.Nv;
-    const float bv = (bias && cvalid) ? bias[col] : 0.f;
+    float bv = (bias && cvalid) ? bias[col] : 0.f;
+    if (EPI == EPI_RESIDUAL_GN && cvalid) bv -= gn_mr * gnv[col];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 64 + 16 * i + 4 * q + r;
         const bool valid = cvalid && (row % g.Tp) < g.Tv;
-        float v = acc[i][j][r] + bv;
+        float v = (EPI == EPI_RESIDUAL_GN ? gn_rstd * acc[i][j][r] : acc[i][j][r]) + bv;
         if (EPI == EPI_PRELU_STATS) v = v > 0.f ? v : slope * v;
         if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-        if (EPI == EPI_RESIDUAL) {
+        if (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_GN) {
           const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
           v += to_f32<T>(res[(size_t)row * g.ldres + col]);
         }
@@ -426,6 +452,37 @@ __global__ void pack_matrix_kernel(const float* __restrict__ src, T* __restrict_
   }
 }
 
+// Wg[n][k] = gamma[k] * W[n][k] (packed like nppc_pack_matrix: [Npad][ldd], zero padded), v[n] = sum_k Wg[n][k] as stored
+// (rounded), u[n] = sum_k beta[k] * W[n][k] + bias[n]; for n_a x n_b equally shaped blocks at constant parameter strides
+// (TCN blocks x branches); u, v laid out [n_a][n_b][Npad]
+template <typename T>
+__global__ __launch_bounds__(64) void pack_sconv_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ bias,
+                                                        T* __restrict__ Wg, float* __restrict__ u, float* __restrict__ v, int N,
+                                                        int K, int Npad, int ldd, int n_b, long ssa, long ssb, long dsa, long dsb) {
+  const int nn = blockIdx.x, ab = blockIdx.y;
+  const size_t so = (size_t)(ab / n_b) * ssa + (size_t)(ab % n_b) * ssb;
+  T* dst = Wg + (size_t)(ab / n_b) * dsa + (size_t)(ab % n_b) * dsb + (size_t)nn * ldd;
+  float su = 0.f, sv = 0.f;
+  for (int k = threadIdx.x; k < ldd; k += 64) {
+    float wg = 0.f;
+    if (nn < N && k < K) {
+      const float w = W[so + (size_t)nn * K + k];
+      wg = gamma[so + k] * w;
+      su += beta[so + k] * w;
+    }
+    const T o = from_f32<T>(wg);
+    dst[k] = o;
+    sv += to_f32<T>(o);
+  }
+  su = wave_sum(su);
+  sv = wave_sum(sv);
+  if (threadIdx.x == 0) {
+    u[(size_t)ab * Npad + nn] = nn < N ? su + bias[so + nn] : 0.f;
+    v[(size_t)ab * Npad + nn] = sv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,10 +495,11 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
   if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   if (epi == EPI_PRELU_STATS && (!slope || !stats)) return NPPC_EBADARG;
   if ((epi == EPI_RESIDUAL || epi == EPI_MASK_POS) && !res) return NPPC_EBADARG;
+  if (epi == EPI_RESIDUAL_GN) return NPPC_EBADARG;            // has its own entry point (nppc_gemm_nt_gn)
   if (ksplit < 1) ksplit = 1;
   if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
-             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit};
+             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f};
   hipStream_t s = (hipStream_t)stream;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   const int lds_path = ((K / ksplit) % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
@@ -476,6 +534,49 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
     return NPPC_EBADARG;
   }
 #undef LAUNCH
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// sconv with the GroupNorm in front of it folded in (EPI_RESIDUAL_GN above):
+//   C = rstd_b * (A Wg^T) - mean_b * rstd_b * v + u + res,   A = the un-normalised depthwise output, stats = its (sum, sumsq)
+int nppc_gemm_nt_gn(int prec, const void* A, long lda, long sA, const void* Wg, long ldb, long sB, void* C, long ldc, long sC,
+                    const float* u, const float* v, long sUV, const void* res, long ldres, long sRes, const double* stats,
+                    long sStats, double cnt, float eps, int R, int N, int K, int Tp, int Tv, int Nv, int batch, void* stream) {
+  if (!A || !Wg || !C || !u || !v || !res || !stats || R <= 0 || N <= 0 || K <= 0 || batch <= 0 || cnt <= 0) return NPPC_EBADARG;
+  if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
+  GemmArgs g{A, lda, sA, Wg, ldb, sB, C, ldc, sC, u, sUV, res, ldres, sRes, nullptr, 0, const_cast<double*>(stats), sStats,
+             R, N, K, Tp, Tv, Nv, 0, 1, v, sUV, cnt, eps};
+  hipStream_t s = (hipStream_t)stream;
+  const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
+  const int lds_path = (K % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
+  dim3 grid(R / 128, lds_path == 128 ? N / 128 : N / 64, batch);
+#define LAUNCH_GN(TT)                                                                                             \
+  do {                                                                                                            \
+    if (lds_path == 128) hipLaunchKernelGGL((gemm_nt_lds_kernel<TT, EPI_RESIDUAL_GN, 128>), grid, dim3(256), 0, s, g);   \
+    else if (lds_path == 64) hipLaunchKernelGGL((gemm_nt_lds_kernel<TT, EPI_RESIDUAL_GN, 64>), grid, dim3(256), 0, s, g); \
+    else hipLaunchKernelGGL((gemm_nt_kernel<TT, EPI_RESIDUAL_GN>), grid, dim3(256), 0, s, g);                      \
+  } while (0)
+  if (prec == NPPC_PREC_BF16) LAUNCH_GN(bf16_t);
+  else if (prec == NPPC_PREC_F32) LAUNCH_GN(float);
+  else return NPPC_EBADARG;
+#undef LAUNCH_GN
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_tcn_pack_sconv(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* u,
+                        float* v, int N, int K, int Npad, int ldd, int n_a, int n_b, long src_stride_a, long src_stride_b,
+                        long dst_stride_a, long dst_stride_b, void* stream) {
+  if (!W || !gamma || !beta || !bias || !Wg || !u || !v || N > Npad || K > ldd || n_a <= 0 || n_b <= 0 || (long)n_a * n_b > 65535)
+    return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(pack_sconv_kernel<bf16_t>, dim3(Npad, n_a * n_b), dim3(64), 0, s, W, gamma, beta, bias, (bf16_t*)Wg, u, v, N,
+                       K, Npad, ldd, n_b, src_stride_a, src_stride_b, dst_stride_a, dst_stride_b);
+  else
+    hipLaunchKernelGGL(pack_sconv_kernel<float>, dim3(Npad, n_a * n_b), dim3(64), 0, s, W, gamma, beta, bias, (float*)Wg, u, v, N, K,
+                       Npad, ldd, n_b, src_stride_a, src_stride_b, dst_stride_a, dst_stride_b);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

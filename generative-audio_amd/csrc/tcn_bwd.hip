@@ -260,6 +260,260 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
   }
 }
 
+
+// =====================================================================================================
+// Fused backward of everything between the two 1x1 convolutions of a TCNBlock:
+//   dA (gradient of the normalised depthwise output a2 = GN2(y2))  ->  dpre1 (gradient of the conv1x1 pre-activation)
+// through GroupNorm-2, PReLU-2, the depthwise dilated convolution, GroupNorm-1 and PReLU-1, in ONE reduce pass and ONE
+// apply pass over the saved activations (y1 = PReLU1 output, y2 = PReLU2 output), instead of five passes with three
+// intermediate gradient tensors.
+//
+// Notation per sample (n = C*Tv valid elements): xh2 = (y2 - mean2) rstd2, p = PReLU2'(y2), xh1 = (y1 - mean1) rstd1,
+//   d xh2 = dA gamma2,  S1 = sum d xh2,  S2 = sum d xh2 xh2,
+//   du    = p rstd2 (d xh2 - S1/n - xh2 S2/n)                       (gradient of the depthwise output before PReLU-2)
+//   dz1[t]= sum_k wd[k] du[t - (k-1) dil]                            (gradient of z1 = GN1(y1))
+//   R1    = sum gamma1 dz1,  R2 = sum gamma1 dz1 xh1,   dy1 = rstd1 (gamma1 dz1 - R1/n - xh1 R2/n),  dpre1 = PReLU1'(y1) dy1
+// GroupNorm-1's sums R1, R2 depend on du, i.e. on S1, S2 -- but LINEARLY: du = f0 - (S1/n) f1 - (S2/n) f2 with
+// f0 = p rstd2 d xh2, f1 = p rstd2, f2 = p rstd2 xh2, and R1 = sum du m1, R2 = sum du m2 with the fields
+//   m1[t] = gamma1 sum_k wd[k] [0 <= t + (k-1) dil < Tv],   m2[t] = gamma1 sum_k wd[k] xh1[t + (k-1) dil]
+// (the depthwise convolution moved onto the other factor).  So ONE pass yields S1, S2 and the six sums
+// A_j = sum f_j m1, B_j = sum f_j m2, and R1 = A0 - (S1/n) A1 - (S2/n) A2, R2 = B0 - (S1/n) B1 - (S2/n) B2 follow.
+// Per-sample sums: fp64 atomics into S[z][b][8] = (S1, S2, A0, A1, A2, B0, B1, B2); per-channel parameter gradients:
+// LDS partials per workgroup + fp32 atomics, as in the kernels above.
+constexpr int MB_SUMS = 8;
+
+struct MidBwdArgs {
+  const void* dA; const void* y2; const void* y1;     // [z][B][Tp][C]
+  const double* st1; const double* st2;               // GroupNorm (sum, sumsq) per sample: [z][B][2]
+  double* S;                                          // [z][B][8]
+  const float* gamma1; const float* beta1; const float* gamma2; const float* beta2; const float* wd;
+  const float* slope1; const float* slope2;
+  void* a2;                                           // reduce pass: GN2(y2) for the sconv weight gradient (may be null)
+  void* dpre1;                                        // apply pass output
+  float* dgamma2; float* dbeta2;                      // reduce pass
+  float* dgamma1; float* dbeta1; float* dwd; float* dbd; float* dslope1; float* dslope2; float* dbias1;   // apply pass
+  int Cc, Tp, Tv, dil; float eps;
+  long sAct, sSt, sP; int RPB;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
+  extern __shared__ float sm[];   // [2][Cc]: dgamma2, dbeta2
+  __shared__ double red[MB_SUMS][4];
+  const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
+  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct;
+  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct;
+  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct;
+  T* a2 = g.a2 ? reinterpret_cast<T*>(g.a2) + (size_t)z * g.sAct : nullptr;
+  const GnCtx c1 = gn_ctx(g.st1 + (size_t)z * g.sSt, b, (double)Cc * Tv, g.eps);
+  const GnCtx c2 = gn_ctx(g.st2 + (size_t)z * g.sSt, b, (double)Cc * Tv, g.eps);
+  const float sl2 = g.slope2[(size_t)z * g.sP];
+  for (int i = threadIdx.x; i < 2 * Cc; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int cpr = Cc / 8, rpi = 256 / cpr;
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  float acc[MB_SUMS];
+#pragma unroll
+  for (int i = 0; i < MB_SUMS; ++i) acc[i] = 0.f;
+  if (tl < rpi) {
+    float g1[8], g2[8], b2[8], w8[3][8], dg[8], db[8];
+    {
+      float w24[24];
+      loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
+      loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
+      loadf8(g.beta2 + (size_t)z * g.sP + c8, b2);
+#pragma unroll
+      for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dg[i] = db[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w8[k][i] = w24[i * 3 + k];
+      }
+    }
+    const int tend = (blockIdx.x + 1) * g.RPB < Tv ? (blockIdx.x + 1) * g.RPB : Tv;
+    for (int t = blockIdx.x * g.RPB + tl; t < tend; t += rpi) {
+      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+      float dv[8], yv[8], x1[3][8];
+      load8<T>(dA + o, dv);
+      load8<T>(y2 + o, yv);
+      bool ok[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int ts = t + (k - 1) * dil;
+        ok[k] = ts >= 0 && ts < Tv;
+        if (ok[k]) load8<T>(y1 + ((size_t)b * Tp + ts) * Cc + c8, x1[k]);
+      }
+      float av[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh2 = (yv[i] - c2.mean) * c2.rstd;
+        const float dxh = dv[i] * g2[i];
+        dg[i] += dv[i] * xh2;
+        db[i] += dv[i];
+        av[i] = xh2 * g2[i] + b2[i];
+        const float pr = (yv[i] > 0.f ? 1.f : sl2) * c2.rstd;
+        const float f0 = pr * dxh, f1 = pr, f2 = pr * xh2;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (ok[k]) {
+            m1 += w8[k][i];
+            m2 += w8[k][i] * ((x1[k][i] - c1.mean) * c1.rstd);
+          }
+        m1 *= g1[i];
+        m2 *= g1[i];
+        acc[0] += dxh;
+        acc[1] += dxh * xh2;
+        acc[2] += f0 * m1; acc[3] += f1 * m1; acc[4] += f2 * m1;
+        acc[5] += f0 * m2; acc[6] += f1 * m2; acc[7] += f2 * m2;
+      }
+      if (a2) store8<T>(a2 + o, av);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(&sm[c8 + i], dg[i]);
+      atomicAdd(&sm[Cc + c8 + i], db[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MB_SUMS; ++i) {
+    const double d = wave_sum((double)acc[i]);
+    if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < MB_SUMS)
+    atomicAdd(g.S + (size_t)z * g.sSt * (MB_SUMS / 2) + (size_t)b * MB_SUMS + threadIdx.x,
+              red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  float* dgamma2 = g.dgamma2 + (size_t)z * g.sP;
+  float* dbeta2 = g.dbeta2 + (size_t)z * g.sP;
+  for (int i = threadIdx.x; i < Cc; i += 256) {
+    atomicAdd(dgamma2 + i, sm[i]);
+    atomicAdd(dbeta2 + i, sm[Cc + i]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
+  extern __shared__ float sm[];   // [7][Cc]: dgamma1, dbeta1, dbias1, dbd, dwd k = 0..2
+  const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
+  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct;
+  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct;
+  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct;
+  T* dpre1 = reinterpret_cast<T*>(g.dpre1) + (size_t)z * g.sAct;
+  const double cnt = (double)Cc * Tv;
+  const GnCtx c1 = gn_ctx(g.st1 + (size_t)z * g.sSt, b, cnt, g.eps);
+  const GnCtx c2 = gn_ctx(g.st2 + (size_t)z * g.sSt, b, cnt, g.eps);
+  const double* S = g.S + (size_t)z * g.sSt * (MB_SUMS / 2) + (size_t)b * MB_SUMS;
+  const double s1d = S[0] / cnt, s2d = S[1] / cnt;
+  const float s1 = (float)s1d, s2 = (float)s2d;
+  const float r1 = (float)((S[2] - s1d * S[3] - s2d * S[4]) / cnt), r2 = (float)((S[5] - s1d * S[6] - s2d * S[7]) / cnt);
+  const float sl1 = g.slope1[(size_t)z * g.sP], sl2 = g.slope2[(size_t)z * g.sP];
+  const float isl1 = 1.f / sl1, isl2 = 1.f / sl2;
+  for (int i = threadIdx.x; i < 7 * Cc; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int cpr = Cc / 8, rpi = 256 / cpr;
+  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
+  float ds1 = 0.f, ds2 = 0.f;
+  if (tl < rpi) {
+    float g1[8], be1[8], g2[8], w8[3][8];
+    float agam[8], abet[8], abias[8], abd[8], aw[3][8];
+    {
+      float w24[24];
+      loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
+      loadf8(g.beta1 + (size_t)z * g.sP + c8, be1);
+      loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
+#pragma unroll
+      for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        agam[i] = abet[i] = abias[i] = abd[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w8[k][i] = w24[i * 3 + k]; aw[k][i] = 0.f; }
+      }
+    }
+    const int tend = (blockIdx.x + 1) * g.RPB < Tp ? (blockIdx.x + 1) * g.RPB : Tp;
+    for (int t = blockIdx.x * g.RPB + tl; t < tend; t += rpi) {
+      float out[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = 0.f;
+      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
+      if (t < Tv) {
+        float yv1[8], dv[3][8], yv2[3][8];
+        load8<T>(y1 + o, yv1);
+        bool ok[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int tu = t - (k - 1) * dil;           // depthwise output frame whose tap k reads frame t
+          ok[k] = tu >= 0 && tu < Tv;
+          if (ok[k]) {
+            const size_t ou = ((size_t)b * Tp + tu) * Cc + c8;
+            load8<T>(dA + ou, dv[k]);
+            load8<T>(y2 + ou, yv2[k]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh1 = (yv1[i] - c1.mean) * c1.rstd;
+          const float z1 = xh1 * g1[i] + be1[i];
+          float dz = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (ok[k]) {
+              const float y = yv2[k][i];
+              const float xh2 = (y - c2.mean) * c2.rstd;
+              const float dy2 = c2.rstd * (dv[k][i] * g2[i] - s1 - xh2 * s2);
+              const float du = y > 0.f ? dy2 : sl2 * dy2;
+              dz += w8[k][i] * du;
+              aw[k][i] += du * z1;
+              if (k == 1) {                             // tu == t: the quantities indexed by the depthwise OUTPUT frame
+                abd[i] += du;
+                if (!(y > 0.f)) ds2 += dy2 * y * isl2;
+              }
+            }
+          agam[i] += dz * xh1;
+          abet[i] += dz;
+          const float dy1 = c1.rstd * (dz * g1[i] - r1 - xh1 * r2);
+          float dp;
+          if (yv1[i] > 0.f) dp = dy1;
+          else { dp = sl1 * dy1; ds1 += dy1 * yv1[i] * isl1; }
+          out[i] = dp;
+          abias[i] += to_f32<T>(from_f32<T>(dp));       // the bias gradient of the STORED (rounded) tensor, as a column sum of it was
+        }
+      }
+      store8<T>(dpre1 + o, out);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(&sm[0 * Cc + c8 + i], agam[i]);
+      atomicAdd(&sm[1 * Cc + c8 + i], abet[i]);
+      atomicAdd(&sm[2 * Cc + c8 + i], abias[i]);
+      atomicAdd(&sm[3 * Cc + c8 + i], abd[i]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) atomicAdd(&sm[(4 + k) * Cc + c8 + i], aw[k][i]);
+    }
+  }
+  const float w1 = wave_sum(ds1), w2 = wave_sum(ds2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(g.dslope1 + (size_t)z * g.sP, w1);
+    atomicAdd(g.dslope2 + (size_t)z * g.sP, w2);
+  }
+  __syncthreads();
+  float* dgamma1 = g.dgamma1 + (size_t)z * g.sP;
+  float* dbeta1 = g.dbeta1 + (size_t)z * g.sP;
+  float* dbias1 = g.dbias1 + (size_t)z * g.sP;
+  float* dbd = g.dbd + (size_t)z * g.sP;
+  float* dwd = g.dwd + (size_t)z * g.sP;
+  for (int i = threadIdx.x; i < Cc; i += 256) {
+    atomicAdd(dgamma1 + i, sm[i]);
+    atomicAdd(dbeta1 + i, sm[Cc + i]);
+    atomicAdd(dbias1 + i, sm[2 * Cc + i]);
+    atomicAdd(dbd + i, sm[3 * Cc + i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(dwd + i * 3 + k, sm[(4 + k) * Cc + i]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,6 +557,35 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
   else
     hipLaunchKernelGGL(dwconv_bwd_kernel<float>, g, dim3(256), smem, s, (const float*)du, (const float*)y1, st1, gamma, beta, wd,
                        (float*)dz, dwd, dbd, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, RPB, noatom);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+
+/* fused backward of a TCNBlock's middle (GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1): dA -> dpre1 and
+ * every parameter gradient of those stages plus the conv1x1 bias gradient, one reduce + one apply launch
+ * (S: [batch][B][8] fp64 workspace, zeroed here; a2 (nullable): GN2(y2) written for the sconv weight gradient) */
+int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, const double* st1, const double* st2, double* S,
+                     const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, const float* wd,
+                     const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
+                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1, int B,
+                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
+  if (!dA || !y2 || !y1 || !st1 || !st2 || !S || !gamma1 || !beta1 || !gamma2 || !beta2 || !wd || !slope1 || !slope2 || !dpre1 ||
+      !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || Cc % 8 || Cc / 8 > 256 ||
+      dil < 1)
+    return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(S, 0, sizeof(double) * MB_SUMS * B * batch, s) != hipSuccess) return NPPC_ELAUNCH;   // [batch][B][8], sSt = 2B
+  MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
+               dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, tcn_rpb()};
+  dim3 g1(ceil_div(Tv, g.RPB), B, batch), g2(ceil_div(Tp, g.RPB), B, batch);
+  if (prec == NPPC_PREC_BF16) {
+    hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, g1, dim3(256), (size_t)2 * Cc * sizeof(float), s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<bf16_t>, g2, dim3(256), (size_t)7 * Cc * sizeof(float), s, g);
+  } else {
+    hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, g1, dim3(256), (size_t)2 * Cc * sizeof(float), s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, g2, dim3(256), (size_t)7 * Cc * sizeof(float), s, g);
+  }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

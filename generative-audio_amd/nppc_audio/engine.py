@@ -12,7 +12,7 @@ import torch
 
 from . import _hip as H
 from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, bwd_head_fusable, lstm2_backward, lstm2_forward,
-                       padded_rows,
+                       own_workspaces, padded_rows,
                        rows_view, workspace)
 
 TCN_HIDDEN = 512
@@ -120,12 +120,15 @@ class FSNEngine:
         self.last_train = None
         self.grad_range_hook = None           # fn(flat_grad, lo, hi): range final for this step (dp.FlatGradientReducer)
         self.bufs = {}
+        own_workspaces(self)                  # step-persistent workspaces keyed by id(self) die with the engine
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
         self.KX = self.lstm.kx
         self.mult = torch.from_numpy(unfold_multiplicity(self.F, self.nb)).to(self.dev)
         C, ldC, ldF = self.C, self.ldC, self.ldF
         self.W1p = torch.zeros(8, 3, TCN_HIDDEN, ldC, dtype=self.dt, device=self.dev)
-        self.W2p = torch.zeros(8, 3, ldC, TCN_HIDDEN, dtype=self.dt, device=self.dev)
+        self.W2p = torch.zeros(8, 3, ldC, TCN_HIDDEN, dtype=self.dt, device=self.dev)      # sconv weights x norm2.weight
+        self.u2 = torch.zeros(8, 3, ldC, dtype=torch.float32, device=self.dev)            # norm2.bias through sconv + sconv.bias
+        self.v2 = torch.zeros(8, 3, ldC, dtype=torch.float32, device=self.dev)            # row sums of W2p
         self.Wfcp = torch.zeros(3, ldF, ldC, dtype=self.dt, device=self.dev)
         self.Opad = rup(self.O, 16)
         self.Whp = torch.zeros(self.Opad, self.Hd, dtype=self.dt, device=self.dev)
@@ -165,7 +168,10 @@ class FSNEngine:
                    dst.stride(1), s)
 
         packed(w1, self.W1p, TCN_HIDDEN, C, TCN_HIDDEN, ldC, 0)
-        packed(w2, self.W2p, C, TCN_HIDDEN, ldC, TCN_HIDDEN, 0)
+        # sconv with norm2 folded in (csrc/tcn.hip: EPI_RESIDUAL_GN): the normalised activation is never materialised
+        H.call("nppc_tcn_pack_sconv", self.prec, w2, self.p("fb_model.sequence_model.0.norm2.weight"),
+               self.p("fb_model.sequence_model.0.norm2.bias"), self.p("fb_model.sequence_model.0.sconv.bias"), self.W2p, self.u2,
+               self.v2, C, TCN_HIDDEN, ldC, TCN_HIDDEN, 8, 3, lay, brs, self.W2p.stride(0), self.W2p.stride(1), s)
         for z, br in enumerate(BRANCHES):
             H.call("nppc_pack_matrix", self.prec, self.p(f"fb_model{br}.fc_output_layer.weight"), self.Wfcp[z], self.F, C,
                    ldF, ldC, 0, s)
@@ -276,11 +282,9 @@ class FSNEngine:
             H.call("nppc_tcn_dwconv", prec, y1, y2, st1, st2, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
                    self.p(pre + "depthwise_conv.weight"), self.p(pre + "depthwise_conv.bias"),
                    self.p(pre + "prelu2.weight"), B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
-            H.call("nppc_tcn_gn_apply", prec, y2, d["a2"], st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"),
-                   B, TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
-            H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, d["a2"], TCN_HIDDEN, sAct, self.W2p[i], TCN_HIDDEN,
-                   ldC * TCN_HIDDEN, Xout, ldC, R * ldC, self.p(pre + "sconv.bias"), sP, Xin, ldC, R * ldC, None, 0,
-                   None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
+            H.call("nppc_gemm_nt_gn", prec, y2, TCN_HIDDEN, sAct, self.W2p[i], TCN_HIDDEN, ldC * TCN_HIDDEN, Xout, ldC, R * ldC,
+                   self.u2[i], self.v2[i], ldC, Xin, ldC, R * ldC, st2, B * 2, float(TCN_HIDDEN * Tv), 1e-8, R, ldC,
+                   TCN_HIDDEN, Tp, Tv, C, 3, s)
         Xlast = d["X"][8 if train else 2]
         # 5: trailing ReLU + Linear(C -> F) + ReLU
         H.call("nppc_gemm_nt", prec, EPI_RELU, Xlast, ldC, R * ldC, self.Wfcp, ldC, ldF * ldC, d["fb"], ldF, R * ldF,
@@ -312,6 +316,7 @@ class FSNEngine:
         if train:
             self._gen += 1
             d["gen"] = self._gen
+            d["consumed"] = False            # the buffer dict is reused by every step of this shape
             self.last_train = d
         return out
 
@@ -502,7 +507,7 @@ class FSNEngine:
         sAct = B * Tp * TCN_HIDDEN
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
-        Sgn = ws("Sgn", (3, B, 2), torch.float64)
+        Smid = ws("Smid", (3, B, 8), torch.float64)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):
             pre = f"fb_model.sequence_model.{i}."
@@ -514,9 +519,20 @@ class FSNEngine:
             else:
                 a2 = d["a2"]
             H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
+            # dA2 = dXo W2  (gradient of the normalised depthwise output)
+            H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
+                   sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
+            # GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1 backward in one reduce + one apply pass: h1b -> h2b
+            # (= gradient of the conv1x1 output) with every parameter gradient of those stages and the conv1x1 bias gradient;
+            # the reduce pass also leaves a2 = GN2(y2), the operand of the sconv weight gradient
+            H.call("nppc_tcn_mid_bwd", prec, h1b, y2, y1, st1, st2, Smid, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
+                   self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), self.p(pre + "depthwise_conv.weight"),
+                   self.p(pre + "prelu1.weight"), self.p(pre + "prelu2.weight"), a2, h2b, self.g(pre + "norm2.weight"),
+                   self.g(pre + "norm2.bias"), self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"),
+                   self.g(pre + "depthwise_conv.weight"), self.g(pre + "depthwise_conv.bias"), self.g(pre + "prelu1.weight"),
+                   self.g(pre + "prelu2.weight"), self.g(pre + "conv1x1.bias"), B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP,
+                   3, s)
             # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
-            H.call("nppc_tcn_gn_apply", prec, y2, a2, st2, self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), B,
-                   TCN_HIDDEN, TCN_HIDDEN, Tp, Tv, 1e-8, sAct, B * 2, sP, 3, s)
             if tn_ok:
                 # row-major operands as they are: slab[k][c] = sum_r a2[r][k] * dXo[r][c] = dW2^T, transposed in the reduction
                 def sconv_wgrad(a2=a2, dXo=dXo, dest=self.g(pre + "sconv.weight")):
@@ -531,23 +547,7 @@ class FSNEngine:
                 H.call("nppc_transpose", prec, a2, tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
                 self._wgrad(tA, R, sTA, tB, R, sTB, Cr, TCN_HIDDEN, R, S2, pre + "sconv.weight", TCN_HIDDEN, C, TCN_HIDDEN,
                             slab2, batch=3, sDst=sP)
-            # dA2 = dXo W2
-            H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
-                   sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
-            # GroupNorm-2 + PReLU-2 backward
-            H.call("nppc_tcn_gn_bwd", prec, h1b, y2, st2, self.p(pre + "norm2.weight"), self.p(pre + "prelu2.weight"), Sgn, h2b,
-                   self.g(pre + "norm2.weight"), self.g(pre + "norm2.bias"), self.g(pre + "prelu2.weight"), B, TCN_HIDDEN, Tp,
-                   Tv, 1e-8, sAct, B * 2, sP, 3, s)
-            # depthwise conv backward (recomputes GN1(y1))
-            H.call("nppc_tcn_dwconv_bwd", prec, h2b, y1, st1, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
-                   self.p(pre + "depthwise_conv.weight"), h1b, self.g(pre + "depthwise_conv.weight"),
-                   self.g(pre + "depthwise_conv.bias"), B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
-            # GroupNorm-1 + PReLU-1 backward
-            H.call("nppc_tcn_gn_bwd", prec, h1b, y1, st1, self.p(pre + "norm1.weight"), self.p(pre + "prelu1.weight"), Sgn, h2b,
-                   self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"), self.g(pre + "prelu1.weight"), B, TCN_HIDDEN, Tp,
-                   Tv, 1e-8, sAct, B * 2, sP, 3, s)
-            # conv1x1: bias, weight, input gradients
-            H.call("nppc_colsum", prec, h2b, self.g(pre + "conv1x1.bias"), R, TCN_HIDDEN, TCN_HIDDEN, sAct, sP, 3, s)
+            # conv1x1: weight, input gradients (the bias gradient came out of the fused kernel)
             if tn_ok:
                 # slab[k][c] = sum_r dpre1[r][k] * Xin[r][c] = dW1
                 def c1_wgrad(h2b=h2b, Xin=Xin, dest=self.g(pre + "conv1x1.weight")):

@@ -35,6 +35,7 @@ class PackedLSTM:
         self.wp2 = torch.empty(n2.value, dtype=dt, device=device)
         self.bias1 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
         self.bias2 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
+        own_workspaces(self)
 
     def pack(self, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
         ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1)]
@@ -69,17 +70,41 @@ def _flag_blocks():
     return [t for k, t in _WS.items() if k[0][-1] == "coop_flags"]
 
 
+_RETIRED_TIMEOUTS = 0      # time-outs counted in flag blocks that have been released with their owner
+
+
 def coop_timeouts():
     """Bounded hand-off spins that gave up since the counters were last cleared (0 on a healthy run).  The counter word
     of every flag block is STICKY: kernels only add to it and no launcher clears it (csrc/lstm_coop.hip), so a time-out
     in ANY earlier launch is still visible here.  Reads the device (one small copy per flag block: call it where the
     host synchronises anyway)."""
-    return sum(int(t[-4].item()) for t in _flag_blocks())
+    return _RETIRED_TIMEOUTS + sum(int(t[-4].item()) for t in _flag_blocks())
 
 
 def clear_coop_timeouts():
+    global _RETIRED_TIMEOUTS
+    _RETIRED_TIMEOUTS = 0
     for t in _flag_blocks():
         t[-4:].zero_()
+
+
+def release_workspaces(owner_id):
+    """drop every step-persistent workspace of one owner (a packed-weight object or an engine; key[1] of its workspace
+    keys is id(owner)).  Registered as a weakref finalizer by the owners, so the tens of GB of saved LSTM state of a
+    deleted model return to the allocator instead of living as long as the process."""
+    global _RETIRED_TIMEOUTS
+    for k in [k for k in _WS if len(k[0]) > 1 and k[0][1] == owner_id]:
+        t = _WS.pop(k)
+        if k[0][-1] == "coop_flags":
+            try:
+                _RETIRED_TIMEOUTS += int(t[-4].item())
+            except Exception:          # interpreter / device shutting down
+                pass
+
+
+def own_workspaces(owner):
+    import weakref
+    weakref.finalize(owner, release_workspaces, id(owner))
 
 
 def check_coop_timeouts(where):
@@ -193,6 +218,7 @@ class PackedLSTMBwd:
         dt = H.dtype_of(prec)
         self.wb1 = torch.empty(n1.value, dtype=dt, device=device)
         self.wb2 = torch.empty(n2.value, dtype=dt, device=device)
+        own_workspaces(self)
         self.coop = prec == H.PREC_BF16 and Hd == 384 and I <= 64
         if self.coop:
             nc = ctypes.c_long()

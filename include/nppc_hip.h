@@ -92,6 +92,26 @@ int nppc_tcn_gn_bwd(int prec, const void* dA, const void* y, const double* st, c
 int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* st1, const float* gamma, const float* beta,
                         const float* wd, void* dz, float* dwd, float* dbd, int B, int Cc, int Tp, int Tv, int dil, float eps,
                         long sAct, long sSt, long sP, int batch, void* stream);
+/* fused backward of a TCNBlock's middle (causal_conv.py:98-106 in reverse: GroupNorm-2, PReLU-2, depthwise dilated conv,
+ * GroupNorm-1, PReLU-1): dA = gradient of GN2's output -> dpre1 = gradient of conv1x1's output, every parameter gradient of
+ * those stages and the conv1x1 bias gradient, in ONE reduce + ONE apply launch (csrc/tcn_bwd.hip).  y1 / y2: the saved PReLU
+ * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][8] fp64 workspace (zeroed by the launcher); a2 (nullable)
+ * receives GN2(y2), the operand of the sconv weight gradient.  Gradients are ACCUMULATED into their destinations. */
+int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, const double* st1, const double* st2, double* S,
+                     const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, const float* wd,
+                     const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
+                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1, int B,
+                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream);
+/* sconv of a TCNBlock with the GroupNorm in front of it (norm2, causal_conv.py:104-106) folded into the product:
+ *   C = rstd_b * (A Wg^T) - mean_b * rstd_b * v + u + res,  A = the un-normalised depthwise output, stats = its per-sample
+ * (sum, sumsq), cnt = elements per sample; nppc_tcn_pack_sconv builds Wg[n][k] = gamma[k] W[n][k], v[n] = sum_k Wg[n][k],
+ * u[n] = sum_k beta[k] W[n][k] + bias[n] for n_a x n_b equally shaped blocks at constant parameter strides */
+int nppc_gemm_nt_gn(int prec, const void* A, long lda, long sA, const void* Wg, long ldb, long sB, void* C, long ldc, long sC,
+                    const float* u, const float* v, long sUV, const void* res, long ldres, long sRes, const double* stats,
+                    long sStats, double cnt, float eps, int R, int N, int K, int Tp, int Tv, int Nv, int batch, void* stream);
+int nppc_tcn_pack_sconv(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* u,
+                        float* v, int N, int K, int Npad, int ldd, int n_a, int n_b, long src_stride_a, long src_stride_b,
+                        long dst_stride_a, long dst_stride_b, void* stream);
 int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long ld_in, long ld_out, long sIn, long sOut,
                    int relu, int batch, void* stream);
 int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,

@@ -1,6 +1,7 @@
 """GPU: size-independent properties at BASELINE's FULL sizes (C2: 32 x 4 s, K=5; C3: inpainting 32 x 4 s), where the
 CPU oracle is too slow to be the checker: linearity / round trips of the transforms, orthogonality of the Gram-Schmidt
 output, loss ranges, determinism, the data-parallel sharding identity, bf16-vs-fp32 agreement of the product itself."""
+import gc
 import os
 import tempfile
 
@@ -91,7 +92,10 @@ def test_train_step_properties_full_size(batch, tmp_path):
         halves = [nppc_base_step(model, (noisy[s], clean[s]), 500, 500, 1.0)[1] for s in (slice(0, 16), slice(16, 32))]
         assert abs(0.5 * (float(halves[0]) + float(halves[1])) - float(obj)) < (2e-3 if precision == "bf16" else 2e-5)
         out[precision] = (float(obj), log["reconst_err"].float().cpu().numpy(), log["pred_crm"].float().cpu().numpy())
-        del model
+        # autograd graphs hold the net: drop them with the model so that its step-persistent workspaces (tens of GB of
+        # saved LSTM state at these sizes) are released before the next model is built
+        del model, rec, obj, obj2, halves, log, w, wc, gram, g
+        gc.collect()
         torch.cuda.empty_cache()
     # the bf16 production mode against the fp32 parity mode of the same product, same weights, full size
     assert abs(out["bf16"][0] - out["fp32"][0]) < 3e-2
@@ -137,7 +141,10 @@ def test_train_step_properties_config5(g_pc, tmp_path):
         torch.cuda.synchronize()
         assert ops_lstm.coop_timeouts() == 0
         out[precision] = (float(obj), log["reconst_err"].float().cpu().numpy(), log["pred_crm"].float().cpu().numpy())
-        del model
+        # autograd graphs hold the net: drop them with the model so that its step-persistent workspaces (tens of GB of
+        # saved LSTM state at these sizes) are released before the next model is built
+        del model, rec, obj, obj2, halves, log, w, wc, gram, g
+        gc.collect()
         torch.cuda.empty_cache()
     if "fp32" in out:
         assert abs(out["bf16"][0] - out["fp32"][0]) < 3e-2

@@ -175,3 +175,28 @@ def test_checkpoint_wire_format_round_trip(tmp_path):
     tr2.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
     for (n1, p1), (n2, p2) in zip(tr.nppc_model.state_dict().items(), tr2.nppc_model.state_dict().items()):
         assert n1 == n2 and np.array_equal(p1.numpy(), p2.numpy())
+
+
+def test_workspaces_die_with_their_owner():
+    """step-persistent workspaces are keyed by id(owner) and released by a finalizer of the owner (a deleted model must
+    give its saved LSTM state back); the sticky hand-off time-out count of a released flag block is kept"""
+    import gc
+    from nppc_audio import ops_lstm
+
+    class Owner:
+        pass
+
+    o = Owner()
+    ops_lstm.own_workspaces(o)
+    n0 = len(ops_lstm._WS)
+    flags = ops_lstm.workspace(("lstm", id(o), True, "coop_flags"), (12,), torch.int32, "cpu", zero=True)
+    flags[-4] = 3
+    ops_lstm.workspace(("lstm", id(o), True, "h1"), (12,), torch.float32, "cpu")
+    assert ops_lstm.workspace(("lstm", id(o), True, "h1"), (12,), torch.float32, "cpu") is ops_lstm._WS[
+        (("lstm", id(o), True, "h1"), (12,), torch.float32, "cpu")]
+    assert len(ops_lstm._WS) == n0 + 2 and ops_lstm.coop_timeouts() == 3
+    del o, flags
+    gc.collect()
+    assert len(ops_lstm._WS) == n0 and ops_lstm.coop_timeouts() == 3
+    ops_lstm.clear_coop_timeouts()
+    assert ops_lstm.coop_timeouts() == 0

@@ -1,0 +1,149 @@
+"""GPU: the fused full-band TCN kernels against fp64 torch autograd of the reference's TCNBlock arithmetic
+(audio_zen/model/module/causal_conv.py:96-108: conv1x1, PReLU, GroupNorm(1, C, eps 1e-8), depthwise dilated conv k = 3,
+PReLU, GroupNorm, sconv, skip) -- the sconv product with GroupNorm-2 folded in (nppc_gemm_nt_gn + nppc_tcn_pack_sconv) and
+the one-reduce-one-apply backward of the block's middle (nppc_tcn_mid_bwd)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-8
+
+
+def _middle(pre1, P, dil, Tv):
+    """pre1 [Z,B,C,Tv] fp64 -> (y1, y2, a2): the block's middle, per branch z"""
+    Z, B, C, _ = pre1.shape
+    y1 = torch.where(pre1 > 0, pre1, P["a1"].view(Z, 1, 1, 1) * pre1)
+    ys, a2s = [], []
+    for z in range(Z):
+        z1 = F.group_norm(y1[z], 1, P["g1"][z], P["b1"][z], EPS)
+        u = F.conv1d(z1, P["wd"][z].view(C, 1, 3), P["bd"][z], padding=dil, dilation=dil, groups=C)
+        y2 = torch.where(u > 0, u, P["a2"][z] * u)
+        ys.append(y2)
+        a2s.append(F.group_norm(y2, 1, P["g2"][z], P["b2"][z], EPS))
+    return y1, torch.stack(ys), torch.stack(a2s)
+
+
+def _tm(x, Tp, dt):
+    """[Z,B,C,Tv] -> time-major zero-padded [Z,B,Tp,C] on the device"""
+    Z, B, C, Tv = x.shape
+    out = torch.zeros(Z, B, Tp, C, dtype=dt, device="cuda")
+    out[:, :, :Tv] = x.permute(0, 1, 3, 2).to(dt).cuda()
+    return out
+
+
+def _stats(x_tm, Tv):
+    v = x_tm[:, :, :Tv].double()
+    return torch.stack([v.sum(dim=(2, 3)), (v * v).sum(dim=(2, 3))], dim=-1).contiguous()     # [Z,B,2]
+
+
+@pytest.mark.parametrize("prec,dil,Tv", [(1, 1, 37), (1, 9, 70), (0, 5, 130), (1, 2, 5)])
+def test_mid_block_backward_matches_autograd(prec, dil, Tv):
+    from nppc_audio import _hip as H
+    Z, B, C, Tp = 3, 2, 64, 256
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(100 * dil + Tv)
+    P = {k: (torch.randn(Z, C, generator=g).double() * s + o) for k, s, o in
+         (("g1", 0.3, 1.0), ("b1", 0.3, 0.0), ("g2", 0.3, 1.0), ("b2", 0.3, 0.0), ("bd", 0.2, 0.0))}
+    P["wd"] = torch.randn(Z, C, 3, generator=g).double() * 0.5
+    P["a1"] = torch.tensor([0.25, 0.1, 0.4], dtype=torch.float64)
+    P["a2"] = torch.tensor([0.3, 0.2, 0.15], dtype=torch.float64)
+    pre1 = torch.randn(Z, B, C, Tv, generator=g).double() * 1.5 + 0.2
+    dA = torch.randn(Z, B, C, Tv, generator=g).double()
+    # the kernel sees the STORED activations: round them to the storage dtype first, differentiate from there
+    y1_0, _, _ = _middle(pre1, P, dil, Tv)
+    y1s = y1_0.to(dt).double()
+    pre1_eff = torch.where(y1s > 0, y1s, y1s / P["a1"].view(Z, 1, 1, 1)).requires_grad_(True)     # PReLU^-1 of the stored y1
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    y1, y2, a2 = _middle(pre1_eff, Pr, dil, Tv)
+    (a2 * dA).sum().backward()
+    y1_tm, y2_tm, dA_tm = _tm(y1.detach(), Tp, dt), _tm(y2.detach(), Tp, dt), _tm(dA, Tp, dt)
+    st1, st2 = _stats(y1_tm, Tv).cuda(), _stats(y2_tm, Tv).cuda()
+    S = torch.empty(Z, B, 8, dtype=torch.float64, device="cuda")
+    flat = lambda t: t.float().contiguous().cuda()
+    sP = 4096                                                    # parameter stride between branches (elements)
+
+    def strided(t):                                              # [Z, n] -> flat buffer with branch stride sP
+        buf = torch.zeros(Z * sP, device="cuda")
+        for z in range(Z):
+            buf[z * sP: z * sP + t[z].numel()] = t[z].reshape(-1).float().cuda()
+        return buf
+
+    par = {k: strided(v) for k, v in P.items()}
+    grads = {k: torch.zeros(Z * sP, device="cuda") for k in ("g2", "b2", "g1", "b1", "wd", "bd", "a1", "a2", "bias1")}
+    a2_out = torch.zeros(Z, B, Tp, C, dtype=dt, device="cuda")
+    dpre1 = torch.full((Z, B, Tp, C), float("nan"), dtype=dt, device="cuda")
+    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
+           par["a1"], par["a2"], a2_out, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
+           grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
+    torch.cuda.synchronize()
+    tol = 2e-4 if prec == 1 else 4e-2
+
+    def rel(got, ref):
+        return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+    want_dpre = pre1_eff.grad.permute(0, 1, 3, 2)                                  # [Z,B,Tv,C]
+    assert bool(torch.isfinite(dpre1.float()).all())
+    assert float(dpre1[:, :, Tv:].float().abs().max()) == 0.0                       # padded frames written as zero
+    assert rel(dpre1[:, :, :Tv], want_dpre) < tol
+    # a2 from stats of the STORED y2 (what the forward used) vs group_norm of the exact y2: storage rounding only
+    assert rel(a2_out[:, :, :Tv], a2.detach().permute(0, 1, 3, 2)) < (1e-5 if prec == 1 else 2e-2)
+    for k, n in (("g2", C), ("b2", C), ("g1", C), ("b1", C), ("wd", 3 * C), ("bd", C), ("a1", 1), ("a2", 1)):
+        got = torch.stack([grads[k][z * sP: z * sP + n] for z in range(Z)])
+        assert rel(got, Pr[k].grad.reshape(Z, n)) < tol, k
+    got_b = torch.stack([grads["bias1"][z * sP: z * sP + C] for z in range(Z)])
+    assert rel(got_b, pre1_eff.grad.sum(dim=(1, 3))) < tol
+    # accumulate semantics: a second launch doubles the parameter gradients
+    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
+           par["a1"], par["a2"], None, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
+           grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
+    torch.cuda.synchronize()
+    got2 = torch.stack([grads["g1"][z * sP: z * sP + C] for z in range(Z)])
+    assert rel(got2, 2 * Pr["g1"].grad) < tol
+
+
+@pytest.mark.parametrize("prec,C,Tv", [(1, 257, 70), (0, 514, 130)])
+def test_sconv_with_folded_groupnorm_matches_reference_arithmetic(prec, C, Tv):
+    """out = sconv(GN2(y2)) + x  (causal_conv.py:104-108) with the normalisation folded into the weights / epilogue"""
+    from nppc_audio import _hip as H
+    Z, B, K, Tp = 3, 2, 512, 128 if Tv <= 128 else 256
+    ldC = (C + 63) // 64 * 64
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(C + Tv)
+    NA, lay, brs = 2, 400_000, 1_000_000                         # two "blocks" x three branches at constant strides
+    n_flat = NA * lay + Z * brs
+    W, gam, bet, bias = (torch.zeros(n_flat) for _ in range(4))
+    ref_p = {}
+    for a in range(NA):
+        for z in range(Z):
+            o = a * lay + z * brs
+            w = torch.randn(C, K, generator=g) * 0.05
+            ga, be, bi = torch.randn(K, generator=g) * 0.3 + 1, torch.randn(K, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2
+            W[o:o + C * K], gam[o:o + K], bet[o:o + K], bias[o:o + C] = w.reshape(-1), ga, be, bi
+            ref_p[a, z] = (w.double(), ga.double(), be.double(), bi.double())
+    Wg = torch.full((NA, Z, ldC, K), 3.0, dtype=dt, device="cuda")
+    u = torch.full((NA, Z, ldC), 3.0, device="cuda")
+    v = torch.full((NA, Z, ldC), 3.0, device="cuda")
+    H.call("nppc_tcn_pack_sconv", prec, W.cuda(), gam.cuda(), bet.cuda(), bias.cuda(), Wg, u, v, C, K, ldC, K, NA, Z, lay, brs,
+           Wg.stride(0), Wg.stride(1), H.stream())
+    a = 1
+    y2 = torch.randn(Z, B, K, Tv, generator=g).double() * 1.3 + 0.4
+    x = torch.randn(Z, B, C, Tv, generator=g).double()
+    y2_tm = torch.zeros(Z, B, Tp, K, dtype=dt, device="cuda")
+    y2_tm[:, :, :Tv] = y2.permute(0, 1, 3, 2).to(dt).cuda()
+    x_tm = torch.zeros(Z, B, Tp, ldC, dtype=dt, device="cuda")
+    x_tm[:, :, :Tv, :C] = x.permute(0, 1, 3, 2).to(dt).cuda()
+    st = _stats(y2_tm, Tv).cuda()
+    out = torch.full((Z, B, Tp, ldC), float("nan"), dtype=dt, device="cuda")
+    R = B * Tp
+    H.call("nppc_gemm_nt_gn", prec, y2_tm, K, R * K, Wg[a], K, ldC * K, out, ldC, R * ldC, u[a], v[a], ldC, x_tm, ldC, R * ldC, st,
+           B * 2, float(K * Tv), EPS, R, ldC, K, Tp, Tv, C, Z, H.stream())
+    torch.cuda.synchronize()
+    assert float(Wg[a, :, C:].float().abs().max()) == 0.0 and float(u[a, :, C:].abs().max()) == 0.0
+    for z in range(Z):
+        w, ga, be, bi = ref_p[a, z]
+        ys = y2_tm[z, :, :Tv].double().cpu().permute(0, 2, 1)                       # stored activations [B,K,Tv]
+        ref = F.conv1d(F.group_norm(ys, 1, ga, be, EPS), w.view(C, K, 1), bi) + x_tm[z, :, :Tv, :C].double().cpu().permute(0, 2, 1)
+        got = out[z, :, :Tv, :C].double().cpu().permute(0, 2, 1)
+        assert float((got - ref).abs().max()) < (2e-5 if prec == 1 else 3e-2) * float(ref.abs().max()), z
+    assert float(out[:, :, Tv:].float().abs().max()) == 0.0 and float(out[:, :, :, C:].float().abs().max()) == 0.0
