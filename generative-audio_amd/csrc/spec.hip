@@ -9,10 +9,15 @@
 namespace {
 
 // one wave per row: sums[r] = sum_t x[r][t]   (fp64 accumulate: the real/imag maps have |mean| << |x|)
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ x, double* __restrict__ sums, long R, int T) {
+// blockIdx.y = map j of a set of equally shaped maps (the 3 or 6 input maps of a net: one launch for all of them)
+struct MapSet { const float* x[6]; };
+
+__global__ __launch_bounds__(256) void rowsum_kernel(MapSet ms, double* __restrict__ sums, long R, int T) {
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const int lane = threadIdx.x & 63;
+  const float* x = ms.x[blockIdx.y];
+  sums += (size_t)blockIdx.y * R;
   const float* p = x + (size_t)r * T;
   double s = 0.0;
   for (int t = lane; t < T; t += 64) s += (double)p[t];
@@ -38,8 +43,18 @@ struct TsseW {
 constexpr int TSSE_MAXC = 1024;
 // blockDim = C rounded up to 64 (<= 1024): with 256 threads a C = 257 map took two trips through every per-channel loop,
 // the second for ONE channel
-__global__ __launch_bounds__(1024) void tsse_fwd_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
-                                                       TsseW w, float* __restrict__ scale, float* __restrict__ ns_out,
+// blockIdx.y = map j = m*3 + z (z: mag / real / imag branch, whose attention weights sit z * sW elements further; m: noisy /
+// enhanced call sharing those weights): rowsum [nmaps][B][C] by j; scale and the saved tensors are laid out [3][nm][B][..]
+__device__ __forceinline__ TsseW tsse_branch(TsseW w, long off) {
+  for (int i = 0; i < 3; ++i) { w.cw[i] += off; if (w.cb[i]) w.cb[i] += off; }
+  w.fcw += off; if (w.fcb) w.fcb += off;
+  w.w1 += off; if (w.b1) w.b1 += off;
+  w.w2 += off; if (w.b2) w.b2 += off;
+  return w;
+}
+
+__global__ __launch_bounds__(1024) void tsse_fwd_kernel(MapSet ms, const double* __restrict__ rowsum,
+                                                       TsseW w, long sW, int nm, float* __restrict__ scale, float* __restrict__ ns_out,
                                                        float* __restrict__ pre_out, float* __restrict__ sq_out,
                                                        float* __restrict__ h1_out, float* __restrict__ sg_out, int C, int C2,
                                                        int T, int la) {
@@ -48,6 +63,19 @@ __global__ __launch_bounds__(1024) void tsse_fwd_kernel(const float* __restrict_
   __shared__ float h1[TSSE_MAXC / 2];
   __shared__ float ns_s;
   const int b = blockIdx.x, tid = threadIdx.x;
+  {
+    const int j = blockIdx.y, z = j % 3, m = j / 3, B = gridDim.x;
+    const size_t slot = (size_t)z * nm + m;
+    w = tsse_branch(w, (long)z * sW);
+    rowsum += (size_t)j * B * C;
+    scale += slot * B * C;
+    if (ns_out) ns_out += slot * B;
+    if (pre_out) pre_out += slot * B * C * 3;
+    if (sq_out) sq_out += slot * B * C;
+    if (h1_out) h1_out += slot * B * C2;
+    if (sg_out) sg_out += slot * B * C;
+  }
+  const float* __restrict__ x = ms.x[blockIdx.y];
   const int Tp = T + la;
   double part = 0.0;
   for (int c = tid; c < C; c += blockDim.x) part += rowsum[(size_t)b * C + c];
@@ -108,11 +136,21 @@ __global__ __launch_bounds__(1024) void tsse_fwd_kernel(const float* __restrict_
 }
 
 // y[b][t][coff + c] = x[b][c][t] * scale[b][c]   for t < T  (rows T..Tp-1 and pad columns stay as the caller left them: zero)
+// batched over the maps of a net: blockIdx.z = b + B * j, j = m*3 + z: source map j, scale [3][nm][B][C], destination
+// branch z (stride sY elements) at column offset m * C
 template <typename T>
-__global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                              T* __restrict__ y, int C, int Tn, int Tp, int ld, int coff) {
+__global__ __launch_bounds__(256) void scale_transpose_kernel(MapSet ms, const float* __restrict__ scale,
+                                                              T* __restrict__ y, int B, int nm, long sY, int C, int Tn, int Tp,
+                                                              int ld, int coff) {
   __shared__ float tile[32][33];
-  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int j = blockIdx.z / B, b = blockIdx.z % B, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const float* __restrict__ x = ms.x[j];
+  {
+    const int z = j % 3, m = j / 3;
+    if (scale) scale += ((size_t)z * nm + m) * B * C;
+    y += (size_t)z * sY;
+    coff += m * C;
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int i = ty; i < 32; i += 8) {
     const int c = c0 + i, t = t0 + tx;
@@ -134,13 +172,23 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const float* __res
 // X0[b][t][coff+c] = x[b][c][t] * ns_b * sg[b][c]  ->  dsg[b][c] = ns_b * sum_t dX0[b][t][coff+c] * x[b][c][t]
 // one workgroup = 64 channels x 64 frames of one sample: x is read along t, dX0 along c (both coalesced), multiplied
 // through an LDS tile; partial sums over the frame chunk go to the ZEROED dsg with one atomic per channel
+// batched: blockIdx.z = b + B * j, j = m*3 + z; dX0 of branch z (stride sY) at column offset m*C; ns [3][nm][B];
+// dsg workspace of map j at j * sWs
 template <typename T>
-__global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ dX0, const float* __restrict__ x,
-                                                          const float* __restrict__ ns, float* __restrict__ dsg, int C, int Tn,
-                                                          int Tp, int ld, int coff) {
+__global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ dX0, MapSet ms,
+                                                          const float* __restrict__ ns, float* __restrict__ dsg, int B, int nm,
+                                                          long sY, long sWs, int C, int Tn, int Tp, int ld, int coff) {
   __shared__ float xt[64][65];
   __shared__ float part[4][64];
-  const int b = blockIdx.z, c0 = blockIdx.x * 64, t0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int j = blockIdx.z / B, b = blockIdx.z % B, c0 = blockIdx.x * 64, t0 = blockIdx.y * 64, tid = threadIdx.x;
+  const float* __restrict__ x = ms.x[j];
+  {
+    const int z = j % 3, m = j / 3;
+    dX0 += (size_t)z * sY;
+    coff += m * C;
+    ns += ((size_t)z * nm + m) * B;
+    dsg += (size_t)j * sWs;
+  }
   for (int e = tid; e < 64 * 64; e += 256) {
     const int cc = e / 64, tt = e % 64;
     xt[cc][tt] = (c0 + cc < C && t0 + tt < Tn) ? x[((size_t)b * C + c0 + cc) * Tn + t0 + tt] : 0.f;
@@ -170,16 +218,39 @@ struct TsseG {
 
 // one workgroup per sample: backprop dsg through sigmoid/fc2/relu/fc1/feature_concate_fc/relu/conv-means;
 // parameter gradients are shared by all samples (and by the noisy/enhanced calls) -> fp32 atomics
-__global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(const float* __restrict__ x, const double* __restrict__ rowsum,
-                                                           TsseW w, TsseG g, const float* __restrict__ ns_in,
+__device__ __forceinline__ TsseG tsse_branch_g(TsseG g, long off) {
+  for (int i = 0; i < 3; ++i) { g.cw[i] += off; g.cb[i] += off; }
+  g.fcw += off; g.fcb += off; g.w1 += off; g.b1 += off; g.w2 += off; g.b2 += off;
+  return g;
+}
+
+// batched: blockIdx.y = map j = m*3 + z; workspace of map j: dsg | da2 | da1 at ws + j * sWs
+__global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(MapSet ms, const double* __restrict__ rowsum,
+                                                           TsseW w, TsseG g, long sW, int nm, const float* __restrict__ ns_in,
                                                            const float* __restrict__ pre, const float* __restrict__ sq,
                                                            const float* __restrict__ h1, const float* __restrict__ sg,
-                                                           const float* __restrict__ dsg, float* __restrict__ da2_ws,
-                                                           float* __restrict__ da1_ws, int C, int C2, int T, int la) {
+                                                           float* __restrict__ ws, long sWs, int C, int C2, int T, int la) {
   __shared__ float da2[TSSE_MAXC];
   __shared__ float da1[TSSE_MAXC / 2];
   __shared__ float dsq[TSSE_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int B = gridDim.x;
+  const float* __restrict__ x = ms.x[blockIdx.y];
+  const float* __restrict__ dsg = ws + (size_t)blockIdx.y * sWs;
+  float* __restrict__ da2_ws = ws + (size_t)blockIdx.y * sWs + (size_t)B * C;
+  float* __restrict__ da1_ws = da2_ws + (size_t)B * C;
+  {
+    const int j = blockIdx.y, z = j % 3, m = j / 3;
+    const size_t slot = (size_t)z * nm + m;
+    w = tsse_branch(w, (long)z * sW);
+    g = tsse_branch_g(g, (long)z * sW);
+    rowsum += (size_t)j * B * C;
+    ns_in += slot * B;
+    pre += slot * B * C * 3;
+    sq += slot * B * C;
+    h1 += slot * B * C2;
+    sg += slot * B * C;
+  }
   const int Tp = T + la;
   const float ns = ns_in[b];
   for (int c = tid; c < C; c += blockDim.x) {
@@ -236,9 +307,19 @@ __global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(const float* __restr
 // fc weight / bias gradients as batched outer products: one thread per weight element sums over the B samples
 // (one atomic per element per call instead of one per element per sample)
 //   w2[c][j] += sum_b da2[b][c] h1[b][j];  b2[c] += sum_b da2[b][c];  w1[j][c] += sum_b da1[b][j] sq[b][c];  b1[j] += sum_b da1[b][j]
-__global__ __launch_bounds__(256) void tsse_bwd_outer_kernel(const float* __restrict__ da2, const float* __restrict__ da1,
+// batched: blockIdx.y = map j = m*3 + z (both calls m of a branch add into the same gradients)
+__global__ __launch_bounds__(256) void tsse_bwd_outer_kernel(const float* __restrict__ ws, long sWs,
                                                              const float* __restrict__ h1, const float* __restrict__ sq, TsseG g,
-                                                             int B, int C, int C2) {
+                                                             long sW, int nm, int B, int C, int C2) {
+  const float* __restrict__ da2 = ws + (size_t)blockIdx.y * sWs + (size_t)B * C;
+  const float* __restrict__ da1 = da2 + (size_t)B * C;
+  {
+    const int j = blockIdx.y, z = j % 3, m = j / 3;
+    const size_t slot = (size_t)z * nm + m;
+    g = tsse_branch_g(g, (long)z * sW);
+    h1 += slot * B * C2;
+    sq += slot * B * C;
+  }
   const int n2 = C * C2;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < n2) {
@@ -268,6 +349,70 @@ __global__ __launch_bounds__(256) void tsse_bwd_outer_kernel(const float* __rest
 
 extern "C" {
 
+/* TSSE backward for ALL input maps of a net in four launches (nmaps = 3 * nm maps, j = m*3 + z): dX0 [3][B][Tp][ld] is the
+ * gradient of the TCN input (branch stride sY), the saved forward tensors are [3][nm][B][..], parameters / gradients of
+ * branch z sit z * sW elements behind the pointers given, ws holds nmaps * B * (2 C + C/2) floats */
+int nppc_tsse_bwd_maps(int prec, const void* dX0, long sY, const float* const* maps, int nmaps, const double* rowsum,
+                       const float* cw0, const float* cw1, const float* cw2, int ks0, int ks1, int ks2, const float* fcw,
+                       const float* w1, const float* w2, long sW, const float* ns, const float* pre, const float* sq,
+                       const float* h1, const float* sg, float* ws, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
+                       float* g_cw2, float* g_cb2, float* g_fcw, float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                       int B, int C, int T, int look_ahead, int Tp, int ld, void* stream) {
+  if (!dX0 || !maps || !rowsum || !ws || B <= 0 || C > TSSE_MAXC || (nmaps != 3 && nmaps != 6)) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  MapSet ms{};
+  for (int j = 0; j < nmaps; ++j) { if (!maps[j]) return NPPC_EBADARG; ms.x[j] = maps[j]; }
+  const int nm = nmaps / 3, C2 = C / 2;
+  const long sWs = (long)B * (2 * C + C2);
+  if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)sWs * nmaps, s) != hipSuccess) return NPPC_ELAUNCH;
+  dim3 g1(ceil_div(C, 64), ceil_div(T, 64), B * nmaps);
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, ms, ns, ws, B, nm, sY, sWs, C, T, Tp, ld, 0);
+  else
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, ms, ns, ws, B, nm, sY, sWs, C, T, Tp, ld, 0);
+  TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
+  TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
+  const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, nmaps), dim3(nt), 0, s, ms, rowsum, w, g, sW, nm, ns, pre, sq, h1, sg, ws, sWs, C,
+                     C2, T, look_ahead);
+  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256), nmaps), dim3(256), 0, s, ws, sWs, h1, sq, g, sW,
+                     nm, B, C, C2);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+/* laplace-norm row sums, TSSE attention and scale + transpose into the TCN input for ALL maps of a net, three launches:
+ * rowsum [nmaps][B][C] (fp64), scale / saved tensors [3][nm][B][..], X0 [3][B][Tp][ld] (branch stride sY), map j = m*3 + z
+ * lands in branch z at columns [m*C, m*C + C) */
+int nppc_tsse_fwd_maps(int prec, const float* const* maps, int nmaps, double* rowsum, const float* cw0, const float* cb0,
+                       const float* cw1, const float* cb1, const float* cw2, const float* cb2, int ks0, int ks1, int ks2,
+                       const float* fcw, const float* fcb, const float* w1, const float* b1, const float* w2, const float* b2, long sW,
+                       float* scale, float* ns, float* pre, float* sq, float* h1, float* sg, void* X0, long sY, int B, int C, int T,
+                       int look_ahead, int Tp, int ld, void* stream) {
+  if (!maps || !rowsum || !scale || !X0 || B <= 0 || C <= 0 || C > TSSE_MAXC || (nmaps != 3 && nmaps != 6)) return NPPC_EBADARG;
+  if (ks0 > T || ks1 > T || ks2 > T) return NPPC_EUNSUPPORTED;
+  const int nm = nmaps / 3;
+  if (nm * C > ld || T > Tp) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  MapSet ms{};
+  for (int j = 0; j < nmaps; ++j) { if (!maps[j]) return NPPC_EBADARG; ms.x[j] = maps[j]; }
+  hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div((long)B * C, 4), nmaps), dim3(256), 0, s, ms, rowsum, (long)B * C, T);
+  TsseW w{{cw0, cw1, cw2}, {cb0, cb1, cb2}, {ks0, ks1, ks2}, fcw, fcb, w1, b1, w2, b2};
+  const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
+  hipLaunchKernelGGL(tsse_fwd_kernel, dim3(B, nmaps), dim3(nt), 0, s, ms, rowsum, w, sW, nm, scale, ns, pre, sq, h1, sg, C, C / 2, T,
+                     look_ahead);
+  dim3 grid(ceil_div(T, 32), ceil_div(C, 32), B * nmaps);
+  if (prec == NPPC_PREC_BF16)
+    hipLaunchKernelGGL(scale_transpose_kernel<bf16_t>, grid, dim3(256), 0, s, ms, scale, (bf16_t*)X0, B, nm, sY, C, T, Tp, ld, 0);
+  else if (prec == NPPC_PREC_F32)
+    hipLaunchKernelGGL(scale_transpose_kernel<float>, grid, dim3(256), 0, s, ms, scale, (float*)X0, B, nm, sY, C, T, Tp, ld, 0);
+  else
+    return NPPC_EBADARG;
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+
 int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsum, const float* cw0, const float* cw1,
                   const float* cw2, int ks0, int ks1, int ks2, const float* fcw, const float* w1, const float* w2,
                   const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws,
@@ -278,28 +423,31 @@ int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsu
   hipStream_t s = (hipStream_t)stream;
   dim3 g1(ceil_div(C, 64), ceil_div(T, 64), B);
   if (hipMemsetAsync(dsg_ws, 0, sizeof(float) * (size_t)B * C, s) != hipSuccess) return NPPC_ELAUNCH;
+  MapSet ms{};
+  ms.x[0] = x;
+  const long sWs1 = (long)B * (2 * C + C / 2);
   if (prec == NPPC_PREC_BF16)
-    hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, ms, ns, dsg_ws, B, 1, 0L, sWs1, C, T, Tp, ld, coff);
   else
-    hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, x, ns, dsg_ws, C, T, Tp, ld, coff);
+    hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, ms, ns, dsg_ws, B, 1, 0L, sWs1, C, T, Tp, ld, coff);
   TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
   TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
   // dsg_ws holds B * (2 C + C/2) floats: dsg [B][C] | da2 [B][C] | da1 [B][C/2]
-  float* da2_ws = dsg_ws + (size_t)B * C;
-  float* da1_ws = da2_ws + (size_t)B * C;
   const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
-  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B), dim3(nt), 0, s, x, rowsum, w, g, ns, pre, sq, h1, sg, dsg_ws, da2_ws, da1_ws,
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, 1), dim3(nt), 0, s, ms, rowsum, w, g, 0L, 1, ns, pre, sq, h1, sg, dsg_ws, sWs1,
                      C, C / 2, T, look_ahead);
   const int C2 = C / 2;
-  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256)), dim3(256), 0, s, da2_ws, da1_ws, h1, sq, g,
-                     B, C, C2);
+  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256), 1), dim3(256), 0, s, dsg_ws, sWs1, h1, sq, g,
+                     0L, 1, B, C, C2);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
 
 int nppc_rowsum(const float* x, double* sums, long R, int T, void* stream) {
   if (!x || !sums || R <= 0 || T <= 0) return NPPC_EBADARG;
-  hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, x, sums, R, T);
+  MapSet ms{};
+  ms.x[0] = x;
+  hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div(R, 4), 1), dim3(256), 0, (hipStream_t)stream, ms, sums, R, T);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
@@ -313,7 +461,9 @@ int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const 
   if (ks0 > T || ks1 > T || ks2 > T) return NPPC_EUNSUPPORTED;
   TsseW w{{cw0, cw1, cw2}, {cb0, cb1, cb2}, {ks0, ks1, ks2}, fcw, fcb, w1, b1, w2, b2};
   const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
-  hipLaunchKernelGGL(tsse_fwd_kernel, dim3(B), dim3(nt), 0, (hipStream_t)stream, x, rowsum, w, scale, ns, pre, sq, h1, sg,
+  MapSet ms{};
+  ms.x[0] = x;
+  hipLaunchKernelGGL(tsse_fwd_kernel, dim3(B, 1), dim3(nt), 0, (hipStream_t)stream, ms, rowsum, w, 0L, 1, scale, ns, pre, sq, h1, sg,
                      C, C / 2, T, look_ahead);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
@@ -323,11 +473,13 @@ int nppc_scale_transpose(int prec, const float* x, const float* scale, void* y, 
                          int coff, void* stream) {
   if (!x || !y || B <= 0 || coff + C > ld || T > Tp) return NPPC_EBADARG;
   dim3 grid(ceil_div(T, 32), ceil_div(C, 32), B);
+  MapSet ms{};
+  ms.x[0] = x;
   if (prec == NPPC_PREC_BF16)
-    hipLaunchKernelGGL(scale_transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, scale, (bf16_t*)y, C, T,
+    hipLaunchKernelGGL(scale_transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, ms, scale, (bf16_t*)y, B, 1, 0L, C, T,
                        Tp, ld, coff);
   else if (prec == NPPC_PREC_F32)
-    hipLaunchKernelGGL(scale_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, scale, (float*)y, C, T, Tp,
+    hipLaunchKernelGGL(scale_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, ms, scale, (float*)y, B, 1, 0L, C, T, Tp,
                        ld, coff);
   else
     return NPPC_EBADARG;

@@ -55,6 +55,13 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
 
 
+def ptr_array(tensors):
+    """host array of device pointers (for entry points that take `const float* const*`)"""
+    for t in tensors:
+        assert t.is_cuda and t.is_contiguous()
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 def dtype_of(prec):
     return torch.bfloat16 if prec == PREC_BF16 else torch.float32
 
@@ -93,6 +100,9 @@ SIGS = {
     "nppc_istft": [P, P, P, I, I, I, I, I, P],
     "nppc_rowsum": [P, P, L, I, P],
     "nppc_tsse_fwd": [P, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "nppc_tsse_fwd_maps": [I, P, I, P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, L, P, P, P, P, P, P, P, L, I, I, I, I, I, I, P],
+    "nppc_tsse_bwd_maps": [I, P, L, P, I, P, P, P, P, I, I, I, P, P, P, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                           I, I, I, I, I, I, P],
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],

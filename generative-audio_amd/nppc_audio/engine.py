@@ -72,6 +72,19 @@ class FlatParams:
             self.grad = torch.zeros_like(self.flat)
         return self.grad
 
+    def attention_stride(self):
+        """element stride between the three (equally shaped) attention layers channel_attention{,_real,_imag}"""
+        names = [n for n, _ in self.named if n.startswith("channel_attention.")]
+        a = self.off["channel_attention." + names[0].split(".", 1)[1]][0]
+        strides = set()
+        for n in names:
+            leaf = n.split(".", 1)[1]
+            o0, o1, o2 = (self.off[f"channel_attention{br}.{leaf}"][0] for br in BRANCHES)
+            strides.add(o1 - o0)
+            strides.add(o2 - o1)
+        assert len(strides) == 1 and a >= 0
+        return strides.pop()
+
     def branch_stride(self):
         a = self.off["fb_model.fc_output_layer.weight"][0]
         b = self.off["fb_model_real.fc_output_layer.weight"][0]
@@ -114,6 +127,7 @@ class FSNEngine:
         self.dev = flat.flat.device
         self.I = 2 * sb_neighbors + 1 + 3
         self.sP = flat.branch_stride()
+        self.sAtt = flat.attention_stride()
         self.packed_version = None
         self._side = None                     # side stream for the LSTM weight-gradient GEMMs (backward)
         self._gen = 0                         # train-forward generation: backward must consume the LATEST train forward
@@ -247,23 +261,16 @@ class FSNEngine:
         maps = [m.contiguous().float() for m in maps]
         d["maps"] = maps if train else None
         sv = d.get("tsse_saved")
-        # 1-3: laplace norm + TSSE attention scale, transposed into the TCN input
-        for z, br in enumerate(BRANCHES):
-            att = f"channel_attention{br}."
-            for m in range(self.nm):
-                x = maps[m * 3 + z]
-                rs = d["rs"][m * 3 + z]
-                H.call("nppc_rowsum", x, rs, B * F, T, s)
-                sav = [sv[k][z, m] if sv else None for k in ("ns", "pre", "sq", "h1", "sg")]
-                H.call("nppc_tsse_fwd", x, rs,
-                       self.p(att + "smallConv1d.0.weight"), self.p(att + "smallConv1d.0.bias"),
-                       self.p(att + "middleConv1d.0.weight"), self.p(att + "middleConv1d.0.bias"),
-                       self.p(att + "largeConv1d.0.weight"), self.p(att + "largeConv1d.0.bias"),
-                       self.ks[0], self.ks[1], self.ks[2],
-                       self.p(att + "feature_concate_fc.weight"), self.p(att + "feature_concate_fc.bias"),
-                       self.p(att + "fc1.weight"), self.p(att + "fc1.bias"), self.p(att + "fc2.weight"),
-                       self.p(att + "fc2.bias"), d["scale"][z, m], *sav, B, F, T, self.la, s)
-                H.call("nppc_scale_transpose", prec, x, d["scale"][z, m], d["X"][0, z], B, F, T, Tp, ldC, m * F, s)
+        # 1-3: laplace norm + TSSE attention scale, transposed into the TCN input: all 3 * n_maps maps in three launches
+        att = "channel_attention."
+        sv_ = [sv[k] if sv else None for k in ("ns", "pre", "sq", "h1", "sg")]
+        H.call("nppc_tsse_fwd_maps", prec, H.ptr_array(maps), 3 * self.nm, d["rs"],
+               self.p(att + "smallConv1d.0.weight"), self.p(att + "smallConv1d.0.bias"),
+               self.p(att + "middleConv1d.0.weight"), self.p(att + "middleConv1d.0.bias"),
+               self.p(att + "largeConv1d.0.weight"), self.p(att + "largeConv1d.0.bias"), self.ks[0], self.ks[1], self.ks[2],
+               self.p(att + "feature_concate_fc.weight"), self.p(att + "feature_concate_fc.bias"),
+               self.p(att + "fc1.weight"), self.p(att + "fc1.bias"), self.p(att + "fc2.weight"), self.p(att + "fc2.bias"),
+               self.sAtt, d["scale"], *sv_, d["X"][0], R * ldC, B, F, T, self.la, Tp, ldC, s)
         if self.nm == 2:
             H.call("nppc_scale_transpose", prec, maps[0], None, d["rawmag"], B, F, T, Tp, ldF, 0, s)
         # 4: eight TCN blocks, the three branches batched over blockIdx.z
@@ -577,21 +584,17 @@ class FSNEngine:
             dXo = dXL[0]
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
         sv = d["tsse_saved"]
-        dsg = ws("dsg", (B * (2 * F + F // 2),), torch.float32)      # dsg | da2 | da1 (csrc/spec.hip: nppc_tsse_bwd)
-        maps = d["maps"]
-        for z, br in enumerate(BRANCHES):
-            att = f"channel_attention{br}."
-            for m in range(self.nm):
-                H.call("nppc_tsse_bwd", prec, dXo[z], maps[m * 3 + z], d["rs"][m * 3 + z],
-                       self.p(att + "smallConv1d.0.weight"), self.p(att + "middleConv1d.0.weight"),
-                       self.p(att + "largeConv1d.0.weight"), self.ks[0], self.ks[1], self.ks[2],
-                       self.p(att + "feature_concate_fc.weight"), self.p(att + "fc1.weight"), self.p(att + "fc2.weight"),
-                       sv["ns"][z, m], sv["pre"][z, m], sv["sq"][z, m], sv["h1"][z, m], sv["sg"][z, m], dsg,
-                       self.g(att + "smallConv1d.0.weight"), self.g(att + "smallConv1d.0.bias"),
-                       self.g(att + "middleConv1d.0.weight"), self.g(att + "middleConv1d.0.bias"),
-                       self.g(att + "largeConv1d.0.weight"), self.g(att + "largeConv1d.0.bias"),
-                       self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
-                       self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"),
-                       self.g(att + "fc2.bias"), B, F, T, self.la, Tp, ldC, m * F, s)
+        dsg = ws("dsg", (3 * self.nm * B * (2 * F + F // 2),), torch.float32)      # per map: dsg | da2 | da1 (csrc/spec.hip)
+        att = "channel_attention."
+        H.call("nppc_tsse_bwd_maps", prec, dXo, R * ldC, H.ptr_array(d["maps"]), 3 * self.nm, d["rs"],
+               self.p(att + "smallConv1d.0.weight"), self.p(att + "middleConv1d.0.weight"), self.p(att + "largeConv1d.0.weight"),
+               self.ks[0], self.ks[1], self.ks[2], self.p(att + "feature_concate_fc.weight"), self.p(att + "fc1.weight"),
+               self.p(att + "fc2.weight"), self.sAtt, sv["ns"], sv["pre"], sv["sq"], sv["h1"], sv["sg"], dsg,
+               self.g(att + "smallConv1d.0.weight"), self.g(att + "smallConv1d.0.bias"),
+               self.g(att + "middleConv1d.0.weight"), self.g(att + "middleConv1d.0.bias"),
+               self.g(att + "largeConv1d.0.weight"), self.g(att + "largeConv1d.0.bias"),
+               self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
+               self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"), self.g(att + "fc2.bias"),
+               B, F, T, self.la, Tp, ldC, s)
         torch.cuda.current_stream().wait_stream(self._side)       # join the LSTM weight-gradient stream
         return G

@@ -41,6 +41,22 @@ int nppc_istft(const float* re, const float* im, float* out, int B, int T, int n
  * audio_zen/model/base_model.py:210-224, audio_zen/model/module/attention_model.py:43-98,
  * fullsubnet_plus.py:158-185, nppc_audio/networks.py:80-112 */
 int nppc_rowsum(const float* x, double* sums, long R, int T, void* stream);
+/* the same for ALL input maps of a net at once (maps: host array of nmaps = 3 or 6 device pointers, map j = m*3 + z with
+ * z the mag / real / imag branch and m the noisy / enhanced call): three launches (row sums, attention, scale + transpose)
+ * instead of three per map.  rowsum [nmaps][B][C]; scale and the saved tensors [3][nm][B][..]; parameters of branch z sit
+ * z * sW elements behind the pointers given; X0 [3][B][Tp][ld] with branch stride sY, map j -> branch z, columns m*C.. */
+int nppc_tsse_fwd_maps(int prec, const float* const* maps, int nmaps, double* rowsum, const float* cw0, const float* cb0,
+                       const float* cw1, const float* cb1, const float* cw2, const float* cb2, int ks0, int ks1, int ks2,
+                       const float* fcw, const float* fcb, const float* w1, const float* b1, const float* w2, const float* b2, long sW,
+                       float* scale, float* ns, float* pre, float* sq, float* h1, float* sg, void* X0, long sY, int B, int C, int T,
+                       int look_ahead, int Tp, int ld, void* stream);
+/* ... and its backward (parameter gradients only: the maps are data), four launches; ws: nmaps * B * (2 C + C/2) floats */
+int nppc_tsse_bwd_maps(int prec, const void* dX0, long sY, const float* const* maps, int nmaps, const double* rowsum,
+                       const float* cw0, const float* cw1, const float* cw2, int ks0, int ks1, int ks2, const float* fcw,
+                       const float* w1, const float* w2, long sW, const float* ns, const float* pre, const float* sq,
+                       const float* h1, const float* sg, float* ws, float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1,
+                       float* g_cw2, float* g_cb2, float* g_fcw, float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                       int B, int C, int T, int look_ahead, int Tp, int ld, void* stream);
 int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const float* cb0, const float* cw1,
                   const float* cb1, const float* cw2, const float* cb2, int ks0, int ks1, int ks2, const float* fcw,
                   const float* fcb, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,

@@ -147,3 +147,75 @@ def test_sconv_with_folded_groupnorm_matches_reference_arithmetic(prec, C, Tv):
         got = out[z, :, :Tv, :C].double().cpu().permute(0, 2, 1)
         assert float((got - ref).abs().max()) < (2e-5 if prec == 1 else 3e-2) * float(ref.abs().max()), z
     assert float(out[:, :, Tv:].float().abs().max()) == 0.0 and float(out[:, :, :, C:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nm,prec", [(1, 1), (2, 0)])
+def test_batched_attention_front_equals_per_map_launches(nm, prec):
+    """nppc_tsse_fwd_maps / nppc_tsse_bwd_maps (all 3 * nm input maps of a net in 3 / 4 launches) against the per-map entry
+    points, which tests/test_forward_gpu.py and the whole-step tests pin to the reference (attention_model.py:43-98)"""
+    from nppc_audio import _hip as H
+    B, C, T, la = 3, 33, 40, 2
+    Tp, ld, C2 = 128, 64 * nm + 64, C // 2
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(7 + nm)
+    sW = 5000                                                     # parameter stride between the three attention layers
+    ks = (3, 5, 10)
+    shapes = dict(cw0=C * ks[0], cb0=C, cw1=C * ks[1], cb1=C, cw2=C * ks[2], cb2=C, fcw=3, fcb=1, w1=C2 * C, b1=C2, w2=C * C2, b2=C)
+    offs, o = {}, 0
+    for k, n in shapes.items():
+        offs[k] = o
+        o += (n + 3) // 4 * 4
+    assert o < sW
+    flat = (torch.randn(3 * sW, generator=g) * 0.3).cuda()
+    P = lambda k, z=0: flat[z * sW + offs[k]:]
+    maps = [(torch.randn(B, C, T, generator=g) * (1.0 if j % 3 == 0 else 0.5) + (0.8 if j % 3 == 0 else 0.01)).cuda().contiguous()
+            for j in range(3 * nm)]
+    s = H.stream()
+    # ---- batched
+    rs = torch.empty(3 * nm, B, C, dtype=torch.float64, device="cuda")
+    scale = torch.empty(3, nm, B, C, device="cuda")
+    sv = {k: torch.empty(3, nm, B, *shp, device="cuda") for k, shp in (("ns", ()), ("pre", (C, 3)), ("sq", (C,)), ("h1", (C2,)), ("sg", (C,)))}
+    X0 = torch.zeros(3, B, Tp, ld, dtype=dt, device="cuda")
+    H.call("nppc_tsse_fwd_maps", prec, H.ptr_array(maps), 3 * nm, rs, P("cw0"), P("cb0"), P("cw1"), P("cb1"), P("cw2"), P("cb2"), *ks,
+           P("fcw"), P("fcb"), P("w1"), P("b1"), P("w2"), P("b2"), sW, scale, sv["ns"], sv["pre"], sv["sq"], sv["h1"], sv["sg"], X0,
+           B * Tp * ld, B, C, T, la, Tp, ld, s)
+    # ---- per map
+    X0r = torch.zeros_like(X0)
+    for z in range(3):
+        for m in range(nm):
+            x = maps[m * 3 + z]
+            rs1 = torch.empty(B, C, dtype=torch.float64, device="cuda")
+            H.call("nppc_rowsum", x, rs1, B * C, T, s)
+            sc1 = torch.empty(B, C, device="cuda")
+            one = {k: torch.empty_like(v[z, m]) for k, v in sv.items()}
+            H.call("nppc_tsse_fwd", x, rs1, P("cw0", z), P("cb0", z), P("cw1", z), P("cb1", z), P("cw2", z), P("cb2", z), *ks,
+                   P("fcw", z), P("fcb", z), P("w1", z), P("b1", z), P("w2", z), P("b2", z), sc1, one["ns"], one["pre"], one["sq"],
+                   one["h1"], one["sg"], B, C, T, la, s)
+            H.call("nppc_scale_transpose", prec, x, sc1, X0r[z], B, C, T, Tp, ld, m * C, s)
+            torch.cuda.synchronize()
+            assert torch.equal(rs[m * 3 + z], rs1) and torch.equal(scale[z, m], sc1), (z, m)
+            for k in sv:
+                assert torch.equal(sv[k][z, m], one[k]), (k, z, m)
+    assert torch.equal(X0, X0r)
+    # ---- backward
+    dX0 = (torch.randn(3, B, Tp, ld, generator=g) * 0.1).to(dt).cuda()
+    nW = 3 * nm * B * (2 * C + C2)
+    ws = torch.empty(nW, device="cuda")
+    G = torch.zeros_like(flat)
+    Gp = lambda k, z=0: G[z * sW + offs[k]:]
+    H.call("nppc_tsse_bwd_maps", prec, dX0, B * Tp * ld, H.ptr_array(maps), 3 * nm, rs, P("cw0"), P("cw1"), P("cw2"), *ks, P("fcw"),
+           P("w1"), P("w2"), sW, sv["ns"], sv["pre"], sv["sq"], sv["h1"], sv["sg"], ws, Gp("cw0"), Gp("cb0"), Gp("cw1"), Gp("cb1"),
+           Gp("cw2"), Gp("cb2"), Gp("fcw"), Gp("fcb"), Gp("w1"), Gp("b1"), Gp("w2"), Gp("b2"), B, C, T, la, Tp, ld, s)
+    Gr = torch.zeros_like(flat)
+    Gq = lambda k, z: Gr[z * sW + offs[k]:]
+    ws1 = torch.empty(B * (2 * C + C2), device="cuda")
+    for z in range(3):
+        for m in range(nm):
+            H.call("nppc_tsse_bwd", prec, dX0[z], maps[m * 3 + z], rs[m * 3 + z], P("cw0", z), P("cw1", z), P("cw2", z), *ks,
+                   P("fcw", z), P("w1", z), P("w2", z), sv["ns"][z, m], sv["pre"][z, m], sv["sq"][z, m], sv["h1"][z, m],
+                   sv["sg"][z, m], ws1, Gq("cw0", z), Gq("cb0", z), Gq("cw1", z), Gq("cb1", z), Gq("cw2", z), Gq("cb2", z),
+                   Gq("fcw", z), Gq("fcb", z), Gq("w1", z), Gq("b1", z), Gq("w2", z), Gq("b2", z), B, C, T, la, Tp, ld, m * C, s)
+    torch.cuda.synchronize()
+    assert float(Gr.abs().max()) > 0
+    # fp32 atomics in a different order: equal to summation noise
+    assert float((G - Gr).abs().max()) < 1e-5 * float(Gr.abs().max())

@@ -24,13 +24,14 @@ def ill_conditioned(n):
 
 def check_against_reference_fp32_gradients(z, meta, got, tag="g500"):
     """the fixtures hold slices (first 4096 elements) of 24 gradient tensors computed by the REFERENCE in fp32.
-    Tolerance, relative to the tensor's max |grad|: 1e-2 for the well-conditioned tensors; 0.3 for the real/imag
-    branches = two fp32 evaluations that are each up to 1.4e-1 from the fp64 truth."""
+    Tolerance, relative to the tensor's max |grad|: 5e-3 for the well-conditioned tensors (measured worst 1.7e-3) and
+    0.1 for the real/imag branches (measured worst 1.6e-2; the reference's own fp32 there is up to 1.4e-1 from the fp64
+    truth, BASELINE.md section 2, so two fp32 evaluations may legitimately differ by that order)."""
     worst = {}
     for n, (amax, l2) in meta[tag + ".grad_absmax_l2"].items():
         g = got[n].grad.detach().float().cpu().numpy().reshape(-1)[:4096]
         worst[n] = float(np.abs(g - z[f"{tag}.grad.{n}"]).max() / (amax + 1e-30))
-    bad = {n: r for n, r in worst.items() if r > (0.3 if ill_conditioned(n) else 1e-2)}
+    bad = {n: r for n, r in worst.items() if r > (0.1 if ill_conditioned(n) else 5e-3)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])
     return worst
 
@@ -54,7 +55,15 @@ def build_model(c, precision, tmp_path):
     return model, wts
 
 
-BF16_GRAD_TOL = 0.15
+_FP64_ORACLE = {}
+
+
+def bf16_grad_tol(n):
+    """bf16 mode, error / max|grad| vs the fp64 oracle for the well-conditioned tensors (table in DESIGN.md section 2):
+    0.2 for weight / bias / GroupNorm tensors (measured worst: attention 0.155, TCN 1x1 / depthwise / norm 0.11, sub-band
+    LSTM + head 0.042); 0.6 for the PReLU slopes, single scalars that are sums over every element of a [B, 512, T'] tensor
+    with heavy cancellation (measured worst 0.49)"""
+    return 0.6 if ".prelu" in n else 0.2
 
 
 @pytest.mark.parametrize("name,precision", [("g0_tiny", "fp32"), ("g1_c1", "fp32"), ("g2_k5", "fp32"),
@@ -90,16 +99,18 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
         w = check_against_reference_fp32_gradients(z, meta, dict(model.named_parameters()))
         print(name, "vs reference fp32 gradients, worst:", sorted(((n.replace("audio_pc_wrapper.net.", ""), f"{r:.1e}")
                                                                      for n, r in w.items()), key=lambda kv: -float(kv[1]))[:5])
-    P = {k: v.double() for k, v in wts.items()}
-    for k, v in P.items():
-        if k.startswith("audio_pc_wrapper"):
-            v.requires_grad_(True)
-    _, obj_o, _ = R.nppc_step(torch.from_numpy(z["noisy"]).double(), torch.from_numpy(z["clean"]).double(), P, c["K"],
-                              step, stft=(c["nfft"], c["hop"], c["nfft"]), g_rest=c["G_rest"], g_pc=c["G_pc"],
-                              sb_neighbors=c["sbn"])
-    names = [k for k in P if P[k].requires_grad]
-    gs = torch.autograd.grad(obj_o, [P[k] for k in names])
-    ref = dict(zip(names, gs))
+    if name not in _FP64_ORACLE:             # shared by the fp32 and bf16 runs of a fixture (a minute of host time each)
+        P = {k: v.double() for k, v in wts.items()}
+        for k, v in P.items():
+            if k.startswith("audio_pc_wrapper"):
+                v.requires_grad_(True)
+        _, obj_o, _ = R.nppc_step(torch.from_numpy(z["noisy"]).double(), torch.from_numpy(z["clean"]).double(), P, c["K"],
+                                  step, stft=(c["nfft"], c["hop"], c["nfft"]), g_rest=c["G_rest"], g_pc=c["G_pc"],
+                                  sb_neighbors=c["sbn"])
+        names = [k for k in P if P[k].requires_grad]
+        gs = torch.autograd.grad(obj_o, [P[k] for k in names])
+        _FP64_ORACLE[name] = (float(obj_o), names, dict(zip(names, gs)))
+    obj_o, names, ref = _FP64_ORACLE[name]
     got = dict(model.named_parameters())
     assert abs(float(obj) - float(obj_o)) < (5e-6 if fp32 else 2e-2)
     worst = {}
@@ -141,7 +152,7 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
                  "tcn." + n.rsplit(".", 2)[-2] if ".sequence_model." in n else "fb_fc")
             fam[k] = max(fam.get(k, 0.0), worst[n])
         print(name, "bf16 worst error / max|grad| per well-conditioned family:", {k: f"{v:.2e}" for k, v in sorted(fam.items())})
-        bad = {n: worst[n] for n in well if worst[n] > BF16_GRAD_TOL}
+        bad = {n: worst[n] for n in well if worst[n] > bf16_grad_tol(n)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
         assert cos > 0.99 and abs(np.sqrt(nn_g / nn_r) - 1) < 0.05
     assert abs(np.sqrt(nn_g) - meta["g500.grad_total_l2"]) < (2e-3 if fp32 else 1e-1) * meta["g500.grad_total_l2"]
