@@ -894,6 +894,11 @@ __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
 #define C2T(i)
 #endif
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not make the wave wait for its outstanding
+// global loads / stores / LDS-DMA (hipcc emits s_waitcnt vmcnt(0) in front of the barrier whenever an LDS-DMA may be in
+// flight, and for pending stores) -- used where everything still in flight is consumed behind a LATER vmcnt(0) + barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
   typedef bf16_t T;
@@ -964,6 +969,9 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   // moved in registers instead of being read from HBM a second time
   auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t, bool carry) {
     if (!prow_ok || t < 0) return;
+#ifdef C2_NO_FETCH
+    return;                               // diagnostic: timing without the saved-state loads (results are garbage)
+#endif
     int tc = tc_;
     asm volatile("" : "+v"(tc));          // keep the per-chunk addresses out of the loop-invariant (spilled) set
     const size_t e = ((size_t)t * N + row0 + prow) * H + cu * HC;
@@ -1184,7 +1192,11 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     dy_dma(t - 1);                                     // HEAD: dY rows of the next (earlier) step
     cell_bwd(sv2, dhrec2, !HEAD, dc2, t, dg2T);
     C2T(0)
+#ifdef C2_RAWBAR
+    lds_barrier();                                     // own dgates complete in LDS; everyone done reading dhrec2
+#else
     __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
+#endif
     C2T(1)
     C2T(2)
     layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
@@ -1193,7 +1205,11 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     fetch(sv2, g2, c2, dh2_src, t - 1, true);          // layer-2 state of the next (earlier) step
     cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
     C2T(9)
+#ifdef C2_RAWBAR
+    lds_barrier();
+#else
     __syncthreads();
+#endif
     C2T(10)
     layer_gemm(0, wr1, ep);                            // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
     C2T(11)

@@ -281,7 +281,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 // Per-sample sums: fp64 atomics into S[z][b][8] = (S1, S2, A0, A1, A2, B0, B1, B2); per-channel parameter gradients:
 // LDS partials per workgroup + fp32 atomics, as in the kernels above.
 constexpr int MB_SUMS = 8;
+constexpr int MB_CG = 64;          // channels per workgroup
+constexpr int MB_FL = 32;          // frame lanes per workgroup (256 threads = 32 frame lanes x 8 threads of 8 channels)
+constexpr int MB_PART_ROWS = 9;    // dgamma2, dbeta2 | dgamma1, dbeta1, dbias1, dbd, dwd k = 0..2
 
+// Work split: one workgroup = one sample x 64 channels x ALL frames.  The depthwise convolution couples frames, so with
+// the whole time axis in one workgroup the shifted rows (t +- dil) are the workgroup's own rows a few iterations away
+// (cache hits, no halo re-reads: frame-chunked workgroups re-read 2 dil of every 64 frames and each ended with 3.6 K
+// per-channel partials), every per-channel sum is complete inside the workgroup, and a frame row of a channel group is one
+// full 128-byte line (bf16).  Per-channel parameter-gradient partials go to part[z][b][9 C + 2 C/64] (rows as
+// MB_PART_ROWS, then the two PReLU-slope partials of each channel group); mid_bwd_finish_kernel sums them over the samples
+// into the gradients -- global atomics from every workgroup onto the same addresses ran at the contended rate.
 struct MidBwdArgs {
   const void* dA; const void* y2; const void* y1;     // [z][B][Tp][C]
   const double* st1; const double* st2;               // GroupNorm (sum, sumsq) per sample: [z][B][2]
@@ -293,88 +303,94 @@ struct MidBwdArgs {
   float* dgamma2; float* dbeta2;                      // reduce pass
   float* dgamma1; float* dbeta1; float* dwd; float* dbd; float* dslope1; float* dslope2; float* dbias1;   // apply pass
   int Cc, Tp, Tv, dil; float eps;
-  long sAct, sSt, sP; int RPB;
+  long sAct, sSt, sP;
+  float* part;
 };
+__host__ __device__ __forceinline__ size_t mb_part_stride(int Cc) { return (size_t)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG) + 6; }
+
+// per-channel partials of a workgroup: 256 threads -> 64 channels.  acc[r][i] of thread (fl, ct) belongs to channel
+// ct*8 + i of row r: LDS atomics (8 frame lanes of a wave hit the same word), then one plain store per channel
+template <int ROWS>
+__device__ __forceinline__ void mb_channel_sums(float (&acc)[ROWS][8], float* sm /* [ROWS][64] */, float* dst /* row 0 */, int Cc,
+                                                int c0, int ct) {
+  for (int i = threadIdx.x; i < ROWS * MB_CG; i += 256) sm[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&sm[r * MB_CG + ct * 8 + i], acc[r][i]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ROWS * MB_CG; i += 256) dst[(size_t)(i / MB_CG) * Cc + c0 + (i % MB_CG)] = sm[i];
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
-  extern __shared__ float sm[];   // [2][Cc]: dgamma2, dbeta2
+  __shared__ float sm[2 * MB_CG];
   __shared__ double red[MB_SUMS][4];
   const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
-  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct;
-  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct;
-  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct;
-  T* a2 = g.a2 ? reinterpret_cast<T*>(g.a2) + (size_t)z * g.sAct : nullptr;
+  const int ct = threadIdx.x & 7, fl = threadIdx.x >> 3, c0 = blockIdx.x * MB_CG, c8 = c0 + ct * 8;
+  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  T* a2 = g.a2 ? reinterpret_cast<T*>(g.a2) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8 : nullptr;
   const GnCtx c1 = gn_ctx(g.st1 + (size_t)z * g.sSt, b, (double)Cc * Tv, g.eps);
   const GnCtx c2 = gn_ctx(g.st2 + (size_t)z * g.sSt, b, (double)Cc * Tv, g.eps);
   const float sl2 = g.slope2[(size_t)z * g.sP];
-  for (int i = threadIdx.x; i < 2 * Cc; i += 256) sm[i] = 0.f;
-  __syncthreads();
-  const int cpr = Cc / 8, rpi = 256 / cpr;
-  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
   float acc[MB_SUMS];
 #pragma unroll
   for (int i = 0; i < MB_SUMS; ++i) acc[i] = 0.f;
-  if (tl < rpi) {
-    float g1[8], g2[8], b2[8], w8[3][8], dg[8], db[8];
-    {
-      float w24[24];
-      loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
-      loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
-      loadf8(g.beta2 + (size_t)z * g.sP + c8, b2);
+  float g1[8], g2[8], b2[8], w8[3][8], ch[2][8];
+  {
+    float w24[24];
+    loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
+    loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
+    loadf8(g.beta2 + (size_t)z * g.sP + c8, b2);
 #pragma unroll
-      for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        dg[i] = db[i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) w8[k][i] = w24[i * 3 + k];
-      }
-    }
-    const int tend = (blockIdx.x + 1) * g.RPB < Tv ? (blockIdx.x + 1) * g.RPB : Tv;
-    for (int t = blockIdx.x * g.RPB + tl; t < tend; t += rpi) {
-      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
-      float dv[8], yv[8], x1[3][8];
-      load8<T>(dA + o, dv);
-      load8<T>(y2 + o, yv);
-      bool ok[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int ts = t + (k - 1) * dil;
-        ok[k] = ts >= 0 && ts < Tv;
-        if (ok[k]) load8<T>(y1 + ((size_t)b * Tp + ts) * Cc + c8, x1[k]);
-      }
-      float av[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xh2 = (yv[i] - c2.mean) * c2.rstd;
-        const float dxh = dv[i] * g2[i];
-        dg[i] += dv[i] * xh2;
-        db[i] += dv[i];
-        av[i] = xh2 * g2[i] + b2[i];
-        const float pr = (yv[i] > 0.f ? 1.f : sl2) * c2.rstd;
-        const float f0 = pr * dxh, f1 = pr, f2 = pr * xh2;
-        float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (ok[k]) {
-            m1 += w8[k][i];
-            m2 += w8[k][i] * ((x1[k][i] - c1.mean) * c1.rstd);
-          }
-        m1 *= g1[i];
-        m2 *= g1[i];
-        acc[0] += dxh;
-        acc[1] += dxh * xh2;
-        acc[2] += f0 * m1; acc[3] += f1 * m1; acc[4] += f2 * m1;
-        acc[5] += f0 * m2; acc[6] += f1 * m2; acc[7] += f2 * m2;
-      }
-      if (a2) store8<T>(a2 + o, av);
-    }
+    for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + (size_t)c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      atomicAdd(&sm[c8 + i], dg[i]);
-      atomicAdd(&sm[Cc + c8 + i], db[i]);
+      ch[0][i] = ch[1][i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w8[k][i] = w24[i * 3 + k];
     }
+  }
+  for (int t = fl; t < Tv; t += MB_FL) {
+    const size_t o = (size_t)t * Cc;
+    float dv[8], yv[8], x1[3][8];
+    load8<T>(dA + o, dv);
+    load8<T>(y2 + o, yv);
+    bool ok[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ts = t + (k - 1) * dil;
+      ok[k] = ts >= 0 && ts < Tv;
+      if (ok[k]) load8<T>(y1 + (size_t)ts * Cc, x1[k]);
+    }
+    float av[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh2 = (yv[i] - c2.mean) * c2.rstd;
+      const float dxh = dv[i] * g2[i];
+      ch[0][i] += dv[i] * xh2;
+      ch[1][i] += dv[i];
+      av[i] = xh2 * g2[i] + b2[i];
+      const float pr = (yv[i] > 0.f ? 1.f : sl2) * c2.rstd;
+      const float f0 = pr * dxh, f1 = pr, f2 = pr * xh2;
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (ok[k]) {
+          m1 += w8[k][i];
+          m2 += w8[k][i] * ((x1[k][i] - c1.mean) * c1.rstd);
+        }
+      m1 *= g1[i];
+      m2 *= g1[i];
+      acc[0] += dxh;
+      acc[1] += dxh * xh2;
+      acc[2] += f0 * m1; acc[3] += f1 * m1; acc[4] += f2 * m1;
+      acc[5] += f0 * m2; acc[6] += f1 * m2; acc[7] += f2 * m2;
+    }
+    if (a2) store8<T>(a2 + o, av);
   }
 #pragma unroll
   for (int i = 0; i < MB_SUMS; ++i) {
@@ -385,22 +401,20 @@ __global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
   if (threadIdx.x < MB_SUMS)
     atomicAdd(g.S + (size_t)z * g.sSt * (MB_SUMS / 2) + (size_t)b * MB_SUMS + threadIdx.x,
               red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
-  float* dgamma2 = g.dgamma2 + (size_t)z * g.sP;
-  float* dbeta2 = g.dbeta2 + (size_t)z * g.sP;
-  for (int i = threadIdx.x; i < Cc; i += 256) {
-    atomicAdd(dgamma2 + i, sm[i]);
-    atomicAdd(dbeta2 + i, sm[Cc + i]);
-  }
+  float* part = g.part + ((size_t)z * gridDim.y + b) * mb_part_stride(Cc);
+  mb_channel_sums<2>(ch, sm, part, Cc, c0, ct);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
-  extern __shared__ float sm[];   // [7][Cc]: dgamma1, dbeta1, dbias1, dbd, dwd k = 0..2
+  __shared__ float sm[7 * MB_CG];
+  __shared__ float sl[2][4];
   const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
-  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct;
-  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct;
-  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct;
-  T* dpre1 = reinterpret_cast<T*>(g.dpre1) + (size_t)z * g.sAct;
+  const int ct = threadIdx.x & 7, fl = threadIdx.x >> 3, c0 = blockIdx.x * MB_CG, c8 = c0 + ct * 8;
+  const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  const T* y1 = reinterpret_cast<const T*>(g.y1) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
+  T* dpre1 = reinterpret_cast<T*>(g.dpre1) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
   const double cnt = (double)Cc * Tv;
   const GnCtx c1 = gn_ctx(g.st1 + (size_t)z * g.sSt, b, cnt, g.eps);
   const GnCtx c2 = gn_ctx(g.st2 + (size_t)z * g.sSt, b, cnt, g.eps);
@@ -410,107 +424,114 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
   const float r1 = (float)((S[2] - s1d * S[3] - s2d * S[4]) / cnt), r2 = (float)((S[5] - s1d * S[6] - s2d * S[7]) / cnt);
   const float sl1 = g.slope1[(size_t)z * g.sP], sl2 = g.slope2[(size_t)z * g.sP];
   const float isl1 = 1.f / sl1, isl2 = 1.f / sl2;
-  for (int i = threadIdx.x; i < 7 * Cc; i += 256) sm[i] = 0.f;
-  __syncthreads();
-  const int cpr = Cc / 8, rpi = 256 / cpr;
-  const int tl = threadIdx.x / cpr, c8 = (threadIdx.x % cpr) * 8;
   float ds1 = 0.f, ds2 = 0.f;
-  if (tl < rpi) {
-    float g1[8], be1[8], g2[8], w8[3][8];
-    float agam[8], abet[8], abias[8], abd[8], aw[3][8];
-    {
-      float w24[24];
-      loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
-      loadf8(g.beta1 + (size_t)z * g.sP + c8, be1);
-      loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
+  float g1[8], be1[8], g2[8], w8[3][8];
+  float ch[7][8];          // dgamma1, dbeta1, dbias1, dbd, dwd k = 0..2
+  {
+    float w24[24];
+    loadf8(g.gamma1 + (size_t)z * g.sP + c8, g1);
+    loadf8(g.beta1 + (size_t)z * g.sP + c8, be1);
+    loadf8(g.gamma2 + (size_t)z * g.sP + c8, g2);
 #pragma unroll
-      for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        agam[i] = abet[i] = abias[i] = abd[i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { w8[k][i] = w24[i * 3 + k]; aw[k][i] = 0.f; }
-      }
-    }
-    const int tend = (blockIdx.x + 1) * g.RPB < Tp ? (blockIdx.x + 1) * g.RPB : Tp;
-    for (int t = blockIdx.x * g.RPB + tl; t < tend; t += rpi) {
-      float out[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = 0.f;
-      const size_t o = ((size_t)b * Tp + t) * Cc + c8;
-      if (t < Tv) {
-        float yv1[8], dv[3][8], yv2[3][8];
-        load8<T>(y1 + o, yv1);
-        bool ok[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int tu = t - (k - 1) * dil;           // depthwise output frame whose tap k reads frame t
-          ok[k] = tu >= 0 && tu < Tv;
-          if (ok[k]) {
-            const size_t ou = ((size_t)b * Tp + tu) * Cc + c8;
-            load8<T>(dA + ou, dv[k]);
-            load8<T>(y2 + ou, yv2[k]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float xh1 = (yv1[i] - c1.mean) * c1.rstd;
-          const float z1 = xh1 * g1[i] + be1[i];
-          float dz = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (ok[k]) {
-              const float y = yv2[k][i];
-              const float xh2 = (y - c2.mean) * c2.rstd;
-              const float dy2 = c2.rstd * (dv[k][i] * g2[i] - s1 - xh2 * s2);
-              const float du = y > 0.f ? dy2 : sl2 * dy2;
-              dz += w8[k][i] * du;
-              aw[k][i] += du * z1;
-              if (k == 1) {                             // tu == t: the quantities indexed by the depthwise OUTPUT frame
-                abd[i] += du;
-                if (!(y > 0.f)) ds2 += dy2 * y * isl2;
-              }
-            }
-          agam[i] += dz * xh1;
-          abet[i] += dz;
-          const float dy1 = c1.rstd * (dz * g1[i] - r1 - xh1 * r2);
-          float dp;
-          if (yv1[i] > 0.f) dp = dy1;
-          else { dp = sl1 * dy1; ds1 += dy1 * yv1[i] * isl1; }
-          out[i] = dp;
-          abias[i] += to_f32<T>(from_f32<T>(dp));       // the bias gradient of the STORED (rounded) tensor, as a column sum of it was
-        }
-      }
-      store8<T>(dpre1 + o, out);
-    }
+    for (int v = 0; v < 3; ++v) loadf8(g.wd + (size_t)z * g.sP + (size_t)c8 * 3 + 8 * v, *reinterpret_cast<float(*)[8]>(&w24[8 * v]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      atomicAdd(&sm[0 * Cc + c8 + i], agam[i]);
-      atomicAdd(&sm[1 * Cc + c8 + i], abet[i]);
-      atomicAdd(&sm[2 * Cc + c8 + i], abias[i]);
-      atomicAdd(&sm[3 * Cc + c8 + i], abd[i]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) atomicAdd(&sm[(4 + k) * Cc + c8 + i], aw[k][i]);
+      for (int r = 0; r < 7; ++r) ch[r][i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w8[k][i] = w24[i * 3 + k];
     }
   }
-  const float w1 = wave_sum(ds1), w2 = wave_sum(ds2);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(g.dslope1 + (size_t)z * g.sP, w1);
-    atomicAdd(g.dslope2 + (size_t)z * g.sP, w2);
-  }
-  __syncthreads();
-  float* dgamma1 = g.dgamma1 + (size_t)z * g.sP;
-  float* dbeta1 = g.dbeta1 + (size_t)z * g.sP;
-  float* dbias1 = g.dbias1 + (size_t)z * g.sP;
-  float* dbd = g.dbd + (size_t)z * g.sP;
-  float* dwd = g.dwd + (size_t)z * g.sP;
-  for (int i = threadIdx.x; i < Cc; i += 256) {
-    atomicAdd(dgamma1 + i, sm[i]);
-    atomicAdd(dbeta1 + i, sm[Cc + i]);
-    atomicAdd(dbias1 + i, sm[2 * Cc + i]);
-    atomicAdd(dbd + i, sm[3 * Cc + i]);
+  for (int t = fl; t < Tp; t += MB_FL) {
+    float out[8];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) atomicAdd(dwd + i * 3 + k, sm[(4 + k) * Cc + i]);
+    for (int i = 0; i < 8; ++i) out[i] = 0.f;
+    const size_t o = (size_t)t * Cc;
+    if (t < Tv) {
+      float yv1[8], dv[3][8], yv2[3][8];
+      load8<T>(y1 + o, yv1);
+      bool ok[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int tu = t - (k - 1) * dil;           // depthwise output frame whose tap k reads frame t
+        ok[k] = tu >= 0 && tu < Tv;
+        if (ok[k]) {
+          load8<T>(dA + (size_t)tu * Cc, dv[k]);
+          load8<T>(y2 + (size_t)tu * Cc, yv2[k]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh1 = (yv1[i] - c1.mean) * c1.rstd;
+        const float z1 = xh1 * g1[i] + be1[i];
+        float dz = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (ok[k]) {
+            const float y = yv2[k][i];
+            const float xh2 = (y - c2.mean) * c2.rstd;
+            const float dy2 = c2.rstd * (dv[k][i] * g2[i] - s1 - xh2 * s2);
+            const float du = y > 0.f ? dy2 : sl2 * dy2;
+            dz += w8[k][i] * du;
+            ch[4 + k][i] += du * z1;
+            if (k == 1) {                             // tu == t: the quantities indexed by the depthwise OUTPUT frame
+              ch[3][i] += du;
+              if (!(y > 0.f)) ds2 += dy2 * y * isl2;
+            }
+          }
+        ch[0][i] += dz * xh1;
+        ch[1][i] += dz;
+        const float dy1 = c1.rstd * (dz * g1[i] - r1 - xh1 * r2);
+        float dp;
+        if (yv1[i] > 0.f) dp = dy1;
+        else { dp = sl1 * dy1; ds1 += dy1 * yv1[i] * isl1; }
+        out[i] = dp;
+        ch[2][i] += to_f32<T>(from_f32<T>(dp));       // the bias gradient of the STORED (rounded) tensor, as a column sum of it was
+      }
+    }
+    store8<T>(dpre1 + o, out);
+  }
+  const float w1 = wave_sum(ds1), w2 = wave_sum(ds2);
+  if ((threadIdx.x & 63) == 0) { sl[0][threadIdx.x >> 6] = w1; sl[1][threadIdx.x >> 6] = w2; }
+  float* part = g.part + ((size_t)z * gridDim.y + b) * mb_part_stride(Cc);
+  mb_channel_sums<7>(ch, sm, part + 2 * (size_t)Cc, Cc, c0, ct);      // (its barriers also publish sl)
+  if (threadIdx.x < 2)
+    part[(size_t)MB_PART_ROWS * Cc + 2 * blockIdx.x + threadIdx.x] = sl[threadIdx.x][0] + sl[threadIdx.x][1] + sl[threadIdx.x][2] + sl[threadIdx.x][3];
+}
+
+// sums the per-workgroup partials over the samples and ADDS them to the parameter gradients of branch blockIdx.y.
+// One workgroup = 64 consecutive partial columns x 16 slices of the sample list (256 contiguous bytes per load instruction).
+__global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int B) {
+  __shared__ float red[16][64];
+  const int z = blockIdx.y, Cc = g.Cc;
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  const int ncg = Cc / MB_CG, ncols = MB_PART_ROWS * Cc + 2 * ncg;
+  const size_t ps = mb_part_stride(Cc);
+  float s = 0.f;
+  if (i < ncols) {
+    const float* p = g.part + (size_t)z * B * ps + i;
+    for (int b = slice; b < B; b += 16) s += p[(size_t)b * ps];
+  }
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice != 0 || i >= ncols) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][col];
+  const size_t zo = (size_t)z * g.sP;
+  if (i >= MB_PART_ROWS * Cc) {                       // PReLU slope partials of the channel groups: a handful of atomics
+    atomicAdd(((i - MB_PART_ROWS * Cc) & 1 ? g.dslope2 : g.dslope1) + zo, s);
+    return;
+  }
+  const int row = i / Cc, c = i % Cc;
+  switch (row) {
+    case 0: g.dgamma2[zo + c] += s; break;
+    case 1: g.dbeta2[zo + c] += s; break;
+    case 2: g.dgamma1[zo + c] += s; break;
+    case 3: g.dbeta1[zo + c] += s; break;
+    case 4: g.dbias1[zo + c] += s; break;
+    case 5: g.dbd[zo + c] += s; break;
+    default: g.dwd[zo + c * 3 + (row - 6)] += s; break;
   }
 }
 
@@ -564,28 +585,37 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
 
 /* fused backward of a TCNBlock's middle (GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1): dA -> dpre1 and
  * every parameter gradient of those stages plus the conv1x1 bias gradient, one reduce + one apply launch
- * (S: [batch][B][8] fp64 workspace, zeroed here; a2 (nullable): GN2(y2) written for the sconv weight gradient) */
+ * (S: [batch][B][8] fp64 workspace, zeroed here; part: nppc_tcn_mid_bwd_part_elems(...) floats of workspace for the
+ * per-workgroup partial sums; a2 (nullable): GN2(y2) written for the sconv weight gradient) */
+int nppc_tcn_mid_bwd_part_elems(int B, int Cc, int Tp, int batch, long* n) {
+  if (!n || B <= 0 || Cc <= 0 || Tp <= 0 || batch <= 0) return NPPC_EBADARG;
+  *n = (long)batch * B * (long)mb_part_stride(Cc);
+  return NPPC_OK;
+}
+
 int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, const double* st1, const double* st2, double* S,
+                     float* part,
                      const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, const float* wd,
                      const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
                      float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1, int B,
                      int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
-  if (!dA || !y2 || !y1 || !st1 || !st2 || !S || !gamma1 || !beta1 || !gamma2 || !beta2 || !wd || !slope1 || !slope2 || !dpre1 ||
-      !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || Cc % 8 || Cc / 8 > 256 ||
-      dil < 1)
+  if (!dA || !y2 || !y1 || !st1 || !st2 || !S || !part || !gamma1 || !beta1 || !gamma2 || !beta2 || !wd || !slope1 || !slope2 || !dpre1 ||
+      !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || dil < 1)
     return NPPC_EBADARG;
+  if (Cc % MB_CG) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(S, 0, sizeof(double) * MB_SUMS * B * batch, s) != hipSuccess) return NPPC_ELAUNCH;   // [batch][B][8], sSt = 2B
   MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
-               dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, tcn_rpb()};
-  dim3 g1(ceil_div(Tv, g.RPB), B, batch), g2(ceil_div(Tp, g.RPB), B, batch);
+               dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part};
+  dim3 grid(Cc / MB_CG, B, batch);
   if (prec == NPPC_PREC_BF16) {
-    hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, g1, dim3(256), (size_t)2 * Cc * sizeof(float), s, g);
-    hipLaunchKernelGGL(mid_bwd_apply_kernel<bf16_t>, g2, dim3(256), (size_t)7 * Cc * sizeof(float), s, g);
+    hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, g);
   } else {
-    hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, g1, dim3(256), (size_t)2 * Cc * sizeof(float), s, g);
-    hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, g2, dim3(256), (size_t)7 * Cc * sizeof(float), s, g);
+    hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), 0, s, g);
   }
+  hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(ceil_div((long)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG), 64), batch), dim3(1024), 0, s, g, B);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

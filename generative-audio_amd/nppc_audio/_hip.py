@@ -62,6 +62,12 @@ def ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def mid_bwd_part_elems(B, C, Tp, batch):
+    n = c_l()
+    call("nppc_tcn_mid_bwd_part_elems", B, C, Tp, batch, ctypes.byref(n))
+    return n.value
+
+
 def dtype_of(prec):
     return torch.bfloat16 if prec == PREC_BF16 else torch.float32
 
@@ -105,7 +111,8 @@ SIGS = {
                            I, I, I, I, I, I, P],
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
-    "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tcn_mid_bwd_part_elems": [I, I, I, I, PL],
+    "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
     "nppc_gemm_nt_gn": [I, P, L, L, P, L, L, P, L, L, P, P, L, P, L, L, P, L, D, F, I, I, I, I, I, I, I, P],
     "nppc_tcn_pack_sconv": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, P],
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],

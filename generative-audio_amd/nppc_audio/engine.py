@@ -515,6 +515,7 @@ class FSNEngine:
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
         Smid = ws("Smid", (3, B, 8), torch.float64)
+        Pmid = ws("Pmid", (H.mid_bwd_part_elems(B, TCN_HIDDEN, Tp, 3),), torch.float32)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):
             pre = f"fb_model.sequence_model.{i}."
@@ -532,7 +533,7 @@ class FSNEngine:
             # GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1 backward in one reduce + one apply pass: h1b -> h2b
             # (= gradient of the conv1x1 output) with every parameter gradient of those stages and the conv1x1 bias gradient;
             # the reduce pass also leaves a2 = GN2(y2), the operand of the sconv weight gradient
-            H.call("nppc_tcn_mid_bwd", prec, h1b, y2, y1, st1, st2, Smid, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
+            H.call("nppc_tcn_mid_bwd", prec, h1b, y2, y1, st1, st2, Smid, Pmid, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
                    self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), self.p(pre + "depthwise_conv.weight"),
                    self.p(pre + "prelu1.weight"), self.p(pre + "prelu2.weight"), a2, h2b, self.g(pre + "norm2.weight"),
                    self.g(pre + "norm2.bias"), self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"),

@@ -60,6 +60,7 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     y1_tm, y2_tm, dA_tm = _tm(y1.detach(), Tp, dt), _tm(y2.detach(), Tp, dt), _tm(dA, Tp, dt)
     st1, st2 = _stats(y1_tm, Tv).cuda(), _stats(y2_tm, Tv).cuda()
     S = torch.empty(Z, B, 8, dtype=torch.float64, device="cuda")
+    part = torch.empty(H.mid_bwd_part_elems(B, C, Tp, Z), device="cuda")
     flat = lambda t: t.float().contiguous().cuda()
     sP = 4096                                                    # parameter stride between branches (elements)
 
@@ -73,7 +74,7 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     grads = {k: torch.zeros(Z * sP, device="cuda") for k in ("g2", "b2", "g1", "b1", "wd", "bd", "a1", "a2", "bias1")}
     a2_out = torch.zeros(Z, B, Tp, C, dtype=dt, device="cuda")
     dpre1 = torch.full((Z, B, Tp, C), float("nan"), dtype=dt, device="cuda")
-    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
+    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], a2_out, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
            grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
     torch.cuda.synchronize()
@@ -94,7 +95,7 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     got_b = torch.stack([grads["bias1"][z * sP: z * sP + C] for z in range(Z)])
     assert rel(got_b, pre1_eff.grad.sum(dim=(1, 3))) < tol
     # accumulate semantics: a second launch doubles the parameter gradients
-    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
+    H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], None, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
            grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
     torch.cuda.synchronize()
