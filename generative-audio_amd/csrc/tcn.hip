@@ -914,6 +914,155 @@ __global__ __launch_bounds__(2 * BM, BM == 128 ? 2 : 1) void gemm_tn_tiled_kerne
 
 }  // namespace
 
+namespace {
+// =====================================================================================================
+// LDS-DMA ring variant of the TN split-K GEMM (256 x 128 output tile, 8 waves as 4 x 2, 64 x 64 per wave).
+// Why: the register-staged kernel above keeps ONE stage of global loads in flight per workgroup (issued at the top of a
+// stage, written to LDS at its end), so every stage waits out most of an HBM round trip: 711 TFLOP/s = 0.28 of the MFMA
+// peak on the LSTM weight-gradient shapes.  Here the operand rows stream global -> LDS directly (`global_load_lds_dwordx4`,
+// no staging registers, no ds_write pass) into a ring of DR_STAGES stages of DR_BR K-rows, DR_STAGES - 1 stages ahead of the
+// MFMAs; a stage is retired with a COUNTED s_waitcnt vmcnt (never 0 in the loop) and ONE raw s_barrier (a __syncthreads()
+// would drain the whole ring: hipcc emits vmcnt(0) in front of it while an LDS-DMA is in flight).
+// LDS image of a stage: A rows [DR_BR][256] bf16 (512 B) then B rows [DR_BR][128] (256 B), each row linear but with its 32-byte
+// chunks XOR-swizzled by key(row) = (row & 3) | ((row >> 3) & 1) << 2: the 8 rows a 32-lane half of ds_read_b64_tr_b16
+// touches then sit on 8 different 32-byte bank groups (un-swizzled they all hit the same 8 banks).  The DMA writes LDS
+// lane-linearly, so the swizzle is applied to each lane's SOURCE address (cdna_hip_programming.md, LDS-DMA caveat).
+constexpr int DR_BM = 256, DR_BN = 128, DR_BR = 64, DR_STAGES = 3;
+constexpr int DR_KS = DR_BR / 32;                        // 32-deep MFMA k-steps per stage
+constexpr int DR_NA = DR_BR * DR_BM * 2 / 1024 / 8, DR_NB = DR_BR * DR_BN * 2 / 1024 / 8;   // 1 KB DMA pieces per wave and stage
+constexpr int DR_A_BYTES = DR_BR * DR_BM * 2, DR_B_BYTES = DR_BR * DR_BN * 2, DR_STAGE_BYTES = DR_A_BYTES + DR_B_BYTES;
+
+__device__ __forceinline__ int dr_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                             long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
+                                                             int nzb, long bsA, long bsB, long bsC) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dr_lds[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z % 8 == 0) {                   // all output tiles of one K slice on ONE XCD (see gemm_tn_tiled_kernel)
+    const unsigned tiles = gridDim.x * gridDim.y;
+    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+    const unsigned xcd = lin & 7, j = lin >> 3;
+    bz = xcd + 8 * (j / tiles);
+    const unsigned t = j % tiles;
+    bx = t % gridDim.x;
+    by = t / gridDim.x;
+  }
+  const unsigned bb = bz / nzb;
+  bz %= nzb;
+  A += (size_t)bb * bsA;
+  B += (size_t)bb * bsB;
+  C += (size_t)bb * bsC;
+  const long m0 = (long)bx * DR_BM, n0 = (long)by * DR_BN;
+  const long rbase = (long)bz * Rz;
+  float* Cz = C + (size_t)bz * slab_stride;
+
+  // ---- this wave's DMA pieces of a stage (1 KB each): A pieces DR_NA * w + h (2 rows of 512 B each), B pieces DR_NB * w + h
+  // (4 rows of 256 B each)
+  const unsigned char* srcA[DR_NA];
+  const unsigned char* srcB[DR_NB];
+#pragma unroll
+  for (int h = 0; h < DR_NA; ++h) {
+    const int row = 2 * (DR_NA * wave + h) + (lane >> 5);
+    const int p = ((lane & 31) * 16) ^ (dr_key(row) << 5);
+    srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbase + row) * lda + m0) + p;
+  }
+#pragma unroll
+  for (int h = 0; h < DR_NB; ++h) {
+    const int row = 4 * (DR_NB * wave + h) + (lane >> 4);
+    const int p = ((lane & 15) * 16) ^ (dr_key(row) << 5);
+    srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbase + row) * ldb + n0) + p;
+  }
+  const long strA = (long)DR_BR * lda * 2, strB = (long)DR_BR * ldb * 2;        // bytes per stage
+  // The three DMAs of a stage go out through inline asm: issued with the builtin, hipcc treats every later ds_read as a
+  // possible reader of the pending LDS write and puts s_waitcnt vmcnt(0) in front of each stage's first fragment read, which
+  // drains the ring (the stage issued a moment earlier included) -- the pipeline this kernel exists for.  Hidden from the
+  // compiler, their completion is counted by hand below (cdna_hip_programming.md section 5.7 item 1: an LDS-DMA has no
+  // VGPR destination, so it is register-safe).  M0 carries the wave-uniform LDS byte address of each 1 KB piece.
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)dr_lds;
+  auto dma = [&](const unsigned char* src, unsigned ldst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+  };
+  auto fill = [&](int slot, long st) {
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * DR_STAGE_BYTES);
+#pragma unroll
+    for (int h = 0; h < DR_NA; ++h) dma(srcA[h] + st * strA, l + (DR_NA * wave + h) * 1024);
+#pragma unroll
+    for (int h = 0; h < DR_NB; ++h) dma(srcB[h] + st * strB, l + DR_A_BYTES + (DR_NB * wave + h) * 1024);
+  };
+  // transposed fragment of k-rows [8 qq, 8 qq + 8) x 16 columns starting at col0 (ds_read_b64_tr_b16, two 4-row halves)
+  const int q4 = i16 >> 2, p4 = i16 & 3;
+  auto tfrag = [&](const unsigned char* tile, int rowbytes, int ks, int col0) -> bf16x8 {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int r_lo = 32 * ks + 8 * qq + q4, r_hi = r_lo + 4;
+    const int cb = col0 * 2 + 8 * p4;
+    const unsigned char* lo_p = tile + r_lo * rowbytes + (cb ^ (dr_key(r_lo) << 5));
+    const unsigned char* hi_p = tile + r_hi * rowbytes + (cb ^ (dr_key(r_hi) << 5));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long nstage = Rz / DR_BR;
+#pragma unroll
+  for (int s0 = 0; s0 < DR_STAGES - 1; ++s0)
+    if (s0 < nstage) fill(s0, s0);
+  int slot = 0;
+  for (long st = 0; st < nstage; ++st) {
+    // stage st has landed once at most the (DR_NA + DR_NB) * (stages issued after it) youngest DMAs of this wave are outstanding
+    static_assert(DR_STAGES == 3 && DR_NA + DR_NB == 6, "the counted waits below are written for a 3-stage ring of 6 pieces");
+    if (st + 1 < nstage) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");      // every wave's pieces of stage st landed; everyone is done reading stage st - 1
+    if (st + DR_STAGES - 1 < nstage) {
+      int fs = slot - 1;
+      if (fs < 0) fs += DR_STAGES;
+      fill(fs, st + DR_STAGES - 1);             // into the slot stage st - 1 occupied
+    }
+    const unsigned char* ta = dr_lds + (size_t)slot * DR_STAGE_BYTES;
+    const unsigned char* tb = ta + DR_A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < DR_KS; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tfrag(ta, DR_BM * 2, ks, wm * 64 + 16 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tfrag(tb, DR_BN * 2, ks, wn * 64 + 16 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are complete before it can reach the next barrier
+    slot = slot + 1 == DR_STAGES ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + 16 * i + 4 * qq + r;
+        const long col = n0 + wn * 64 + 16 * j + i16;
+        Cz[row * ldc + col] = acc[i][j][r];
+      }
+}
+
+}  // namespace
+
 // C_slab[z] [M][N] = A[rows slice z][M]^T * B[rows slice z][N]  (bf16 operands, fp32 slabs).  M % 128 == 0,
 // N % 64 == 0, R % (64*ksplit) == 0, lda/ldb multiples of 8.
 // 256-row tiles are on unless NPPC_TN_BIG=0 (A/B switch for tools/bench_tn.py)
@@ -926,11 +1075,38 @@ static bool tn_big_tiles() {
   return v == 1;
 }
 
+// NPPC_TN_DMA=0 switches the LDS-DMA ring kernel off (A/B switch for tools/bench_tn.py)
+static bool tn_dma() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NPPC_TN_DMA");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                      int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  // LDS-DMA ring kernel: plain (ntap == 1) products with 256 x 128 tiles and 32-row stages, enough workgroups to fill the chip
+  if (ntap == 1 && tn_dma() && M % DR_BM == 0 && N % DR_BN == 0 && (R / ksplit) % DR_BR == 0 &&
+      (long)(M / DR_BM) * (N / DR_BN) * ksplit * batch >= 256) {
+    static bool attr = false;
+    constexpr int smem = DR_STAGES * DR_STAGE_BYTES;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+          hipSuccess)
+        return NPPC_ELAUNCH;
+      attr = true;
+    }
+    dim3 grid(M / DR_BM, N / DR_BN, ksplit * batch);
+    hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (long)M * ldc,
+                       R / ksplit, ksplit, sA, sB, sC);
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
   // 256-row tiles (+4...11 % at these shapes) only when they still give every CU a few workgroups
   if (N % 128 == 0 && M % 256 == 0 && tn_big_tiles() && (long)(M / 256) * (N / 128) * ksplit * ntap * batch >= 1024) {
     dim3 grid(M / 256, N / 128, ksplit * ntap * batch);

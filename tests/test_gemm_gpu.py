@@ -5,7 +5,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N,R,S", [(128, 64, 256, 1), (256, 128, 1024, 4), (1536, 384, 2048, 2), (128, 192, 640, 2)])
+# the last three shapes are large enough (>= 256 workgroups of 256 x 128) for the LDS-DMA ring kernel, one of them with a
+# K slice shorter than the ring (2 stages) and one with a slice that is not a multiple of the ring depth
+@pytest.mark.parametrize("M,N,R,S", [(128, 64, 256, 1), (256, 128, 1024, 4), (1536, 384, 2048, 2), (128, 192, 640, 2),
+                                     (1536, 384, 8192, 64), (512, 256, 8192, 128), (1536, 384, 64 * 416, 16)])
 def test_gemm_tn_splitk_matches_matmul(M, N, R, S):
     from nppc_audio import _hip as H
     g = torch.Generator().manual_seed(M + N)
