@@ -936,7 +936,7 @@ __device__ __forceinline__ int dr_key(int row) { return (row & 3) | (((row >> 3)
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                              long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
-                                                             int nzb, long bsA, long bsB, long bsC) {
+                                                             int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char dr_lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
@@ -1015,6 +1015,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // rowsum (optional): sum_r A[r][m] over the K slice -- the A fragments times an all-ones B fragment, by the waves that
+  // hold column tile 0 (one extra MFMA per four): a bias gradient comes out of the weight-gradient product that reads the
+  // same gate gradients, instead of out of a second pass over them
+  const bool do_rowsum = rowsum != nullptr && by == 0 && wn == 0;
+  f32x4 racc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short ones_t;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
   const long nstage = Rz / DR_BR;
 #pragma unroll
@@ -1045,6 +1054,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) racc[i] = mma16(af[i], ones, racc[i]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are complete before it can reach the next barrier
     slot = slot + 1 == DR_STAGES ? 0 : slot + 1;
@@ -1059,6 +1072,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
         const long col = n0 + wn * 64 + 16 * j + i16;
         Cz[row * ldc + col] = acc[i][j][r];
       }
+  if (do_rowsum && i16 == 0) {                      // every column of racc holds the row sum: lane column 0 stores it
+    float* rs = rowsum + ((size_t)bb * nzb + bz) * ((size_t)gridDim.x * DR_BM);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[m0 + wm * 64 + 16 * i + 4 * qq + r] = racc[i][r];
+  }
 }
 
 }  // namespace
@@ -1086,7 +1106,8 @@ static bool tn_dma() {
 }
 
 static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
-                     int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0) {
+                     int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0,
+                     float* rowsum = nullptr) {
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -1103,10 +1124,11 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
     }
     dim3 grid(M / DR_BM, N / DR_BN, ksplit * batch);
     hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (long)M * ldc,
-                       R / ksplit, ksplit, sA, sB, sC);
+                       R / ksplit, ksplit, sA, sB, sC, rowsum);
     NPPC_CHECK_LAUNCH();
     return NPPC_OK;
   }
+  if (rowsum) return NPPC_EUNSUPPORTED;            // only the LDS-DMA kernel produces row sums
   // 256-row tiles (+4...11 % at these shapes) only when they still give every CU a few workgroups
   if (N % 128 == 0 && M % 256 == 0 && tn_big_tiles() && (long)(M / 256) * (N / 128) * ksplit * ntap * batch >= 1024) {
     dim3 grid(M / 256, N / 128, ksplit * ntap * batch);
@@ -1128,6 +1150,15 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
 extern "C" int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
                                    int ksplit, void* stream) {
   return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream);
+}
+
+// The same product plus rowsum[z][m] = sum over the rows of slice z of A[r][m] (fp32, [ksplit][M]): the bias gradient that
+// belongs to a weight gradient, from the same pass over the gate gradients.  Needs the LDS-DMA kernel's shapes
+// (M % 256 == 0, N % 128 == 0, (R / ksplit) % 64 == 0, >= 256 workgroups); NPPC_EUNSUPPORTED otherwise.
+extern "C" int nppc_gemm_tn_splitk_rowsum(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
+                                          int ksplit, float* rowsum, void* stream) {
+  if (!rowsum) return NPPC_EBADARG;
+  return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream, 1, 0, 0, 0, rowsum);
 }
 
 // `batch` independent products in one launch (operand / slab strides in elements; slabs of batch b start at C + b*sC)

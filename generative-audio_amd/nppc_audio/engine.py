@@ -357,7 +357,10 @@ class FSNEngine:
         H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, dst, dst_ld, out_rows, col0, ncols, permH, accumulate,
                S * rows * ncolsN, sDst, batch, s)
 
-    def _lstm_wgrad(self, dg1, dg2, x_rows, h1_rows, h2_rows, Tv, Nseq):
+    def _lstm_wgrad(self, dg1, dg2, x_rows, h1_rows, h2_rows, Tv, Nseq, head=None):
+        """LSTM weight / bias gradients from the row-major gate gradients (runs on the side stream).
+        head = (dyt_rows [Rpad][16] bf16, O): also the output head's weight / bias gradients, as one more TN product
+        h2^T . dY (the 16-column dY rows are read as a 64-column operand: the extra columns are ignored)."""
         s = H.stream()
         dt, dev, Hd, I, KX = self.dt, self.dev, self.Hd, self.I, self.KX
         K4 = 4 * Hd
@@ -387,10 +390,28 @@ class FSNEngine:
             S = WGRAD_SPLITS
             assert 64 * S <= ROW_PAD                 # operand buffers are padded by ROW_PAD rows (ops_lstm.padded_rows)
             slab = ws("slab", (S * K4 * max(Hd, KX),), torch.float32)
+            # the layer-2 bias gradient (column sums of dg2) comes out of the W_ih_l1 product as row sums of its A operand
+            # (LDS-DMA kernel, csrc/tcn.hip) instead of out of a 64-column product of its own that re-read all of dg2
+            fold_bias = K4 % 256 == 0 and Hd % 128 == 0 and (K4 // 256) * (Hd // 128) * S >= 256
             for dg, off, inp, width, dest in jobs:
                 rows = (Rr - off + 64 * S - 1) // (64 * S) * (64 * S)
-                H.call("nppc_gemm_tn_splitk", dg.view(-1)[off * K4:], K4, inp, width, slab, width, K4, width, rows, S, s)
+                if fold_bias and dest[0] == "bias":
+                    continue
+                if fold_bias and dest == ("w", q + "weight_ih_l1"):
+                    rsum = ws("rowsum", (S, K4), torch.float32)
+                    H.call("nppc_gemm_tn_splitk_rowsum", dg.view(-1)[off * K4:], K4, inp, width, slab, width, K4, width, rows, S,
+                           rsum, s)
+                    H.call("nppc_reduce_slabs", rsum, S, K4, 1, self.g(q + "bias_ih_l1"), 1, K4, 0, 1, Hd, 0, 0, 0, 1, s)
+                    self.g(q + "bias_hh_l1").copy_(self.g(q + "bias_ih_l1"))
+                else:
+                    H.call("nppc_gemm_tn_splitk", dg.view(-1)[off * K4:], K4, inp, width, slab, width, K4, width, rows, S, s)
                 scatter(slab, S, K4, width, dest)
+            if head is not None:
+                dyt_rows, O = head
+                rows = (Rr + 64 * S - 1) // (64 * S) * (64 * S)
+                H.call("nppc_gemm_tn_splitk", h2_rows, Hd, dyt_rows, 16, slab, 64, Hd, 64, rows, S, s)
+                H.call("nppc_reduce_slabs_t", slab, S, Hd * 64, 64, self.g("sb_model.fc_output_layer.weight"), Hd, O, Hd, 0, 0, 1, s)
+                H.call("nppc_colsum", self.prec, dyt_rows, self.g("sb_model.fc_output_layer.bias"), Rr, O, 16, 0, 0, 1, s)
             return
         # generic path (fp32 parity mode, small hidden sizes): transposed copies + the NT split-K GEMM
         bk = 64 if self.prec == H.PREC_BF16 else 32
@@ -441,12 +462,18 @@ class FSNEngine:
         ws = lambda name, shape, dtype=dt, zero=False: workspace(("eng", id(self), name), shape, dtype, dev, zero)
         if FUSED_HEAD >= 3 and prec == H.PREC_BF16 and O <= 16 and bwd_head_fusable(Nseq, self.lstm_bwd):
             # the K-split cooperative kernel forms d h2 = dY . Wh itself from the gathered dY rows: no dh2 tensor
-            dyt = ws("dyt", (Tv, Nseq, 16))
+            # dY rows [T'*N][16] (zero padded like the other GEMM operands: the head's weight gradient h2^T . dY runs with
+            # the LSTM weight gradients on the side stream, behind the recurrence, instead of in front of it)
+            dyt_rows = ws("dyt_rows", (padded_rows(Tv * Nseq) + 8, 16), zero=True)
+            dyt = rows_view(dyt_rows, Tv, Nseq)
             H.call("nppc_head_dy_gather", dout, dyt, Nseq, Tv, self.la, O, Fo, s)
-            H.call("nppc_sb_head_bwd_w", prec, dout, lo["h2"], self.g("sb_model.fc_output_layer.weight"),
-                   self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
+            head_wgrad = (dyt_rows, O) if (Hd % 128 == 0 and self.KX % 64 == 0) else None
+            if head_wgrad is None:
+                H.call("nppc_sb_head_bwd_w", prec, dout, lo["h2"], self.g("sb_model.fc_output_layer.weight"),
+                       self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
             dx, dg1, dg2 = lstm2_backward(lo, None, self.lstm_bwd, self.KX, head=(dyt, self.WhT))
         else:
+            head_wgrad = None
             dh2 = ws("dh2", (Tv, Nseq, Hd))
             H.call("nppc_sb_head_bwd", prec, dout, self.WhT, lo["h2"], dh2, self.g("sb_model.fc_output_layer.weight"),
                    self.g("sb_model.fc_output_layer.bias"), Nseq, Tv, self.la, Hd, O, Fo, s)
@@ -462,7 +489,7 @@ class FSNEngine:
             self._side = torch.cuda.Stream(device=dev)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq)
+            self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq, head=head_wgrad)
             if self.grad_range_hook is not None:
                 # the sub-band segment (LSTM + head: the tail of the flat buffer) is final once these GEMMs are done
                 self.grad_range_hook(G, self.fp.off["sb_model.sequence_model.weight_ih_l0"][0], G.numel())

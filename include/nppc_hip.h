@@ -87,6 +87,11 @@ int nppc_gemm_nt_splitk(int prec, const void* A, long lda, const void* B, long l
  * LDS tiles read back with ds_read_b64_tr_b16; M % 128 == 0, N % 64 == 0, R % (64*ksplit) == 0 */
 int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                         void* stream);
+/* the same plus rowsum[z][m] = sum over the rows of slice z of A[r][m] ([ksplit][M] fp32): the bias gradient of an LSTM
+ * layer out of the weight-gradient product that reads the same gate gradients (LDS-DMA kernel shapes only: M % 256 == 0,
+ * N % 128 == 0, (R / ksplit) % 64 == 0, at least 256 workgroups; NPPC_EUNSUPPORTED otherwise) */
+int nppc_gemm_tn_splitk_rowsum(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
+                               int ksplit, float* rowsum, void* stream);
 int nppc_gemm_tn_splitk_batched(const void* A, long lda, long sA, const void* B, long ldb, long sB, float* C, long ldc, long sC,
                                 int M, int N, long R, int ksplit, int batch, void* stream);
 int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,

@@ -82,3 +82,24 @@ def test_pack_matrix_batched_equals_per_matrix_packs():
                 src = flat[a * lay + b * brs: a * lay + b * brs + N * K].reshape(shape)
                 ref = (src if not tr else src.t()).to(torch.bfloat16)
                 assert torch.equal(one[:N, :K], ref) and float(one[N:].abs().max()) == 0.0
+
+
+def test_gemm_tn_rowsum_is_the_column_sum_of_the_a_operand():
+    """nppc_gemm_tn_splitk_rowsum: the product of the LDS-DMA kernel plus sum_r A[r][m] per K slice (the LSTM bias gradient
+    that rides on a weight-gradient product); unsupported shapes are refused, not silently computed without the sums"""
+    from nppc_audio import _hip as H
+    M, N, R, S = 1536, 384, 64 * 64 * 3, 64
+    g = torch.Generator().manual_seed(3)
+    A = (torch.randn(R, M, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    B = torch.randn(R, N, generator=g).cuda().to(torch.bfloat16)
+    C = torch.empty(S, M, N, dtype=torch.float32, device="cuda")
+    rs = torch.full((S, M), float("nan"), device="cuda")
+    H.call("nppc_gemm_tn_splitk_rowsum", A, M, B, N, C, N, M, N, R, S, rs, H.stream())
+    torch.cuda.synchronize()
+    ref = A.float().t().cpu().double() @ B.float().cpu().double()
+    assert (C.sum(0).cpu().double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    want = A.float().view(S, R // S, M).double().sum(dim=1).cpu()
+    assert bool(torch.isfinite(rs).all())
+    assert float((rs.cpu().double() - want).abs().max()) < 1e-3 * float(want.abs().max())
+    with pytest.raises(RuntimeError, match="unsupported"):
+        H.call("nppc_gemm_tn_splitk_rowsum", A, M, B, N, C, N, 128, 64, 1024, 2, rs, H.stream())
