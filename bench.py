@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the precision-matched fp32 steps")
     ap.add_argument("--no-families", action="store_true", help="skip the per-launch HIP-event pass")
+    ap.add_argument("--pipeline", action="store_true", help="pipeline_update mode of the trainer (A/B switch)")
     ap.add_argument("--dp-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dp-selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -293,8 +294,10 @@ def main():
 
     if rank == 0:
         log(f"model built; {a.warmup} warm-up + {a.steps} timed steps, {frames} frames/step/GPU")
+    tr.pipeline_update = a.pipeline              # park a step's tail in front of the next step's restorer LSTM (no gain on one GPU)
     for _ in range(a.warmup):
         tr.train_step(batch)
+    tr.flush()
     sync()
     if rank == 0:
         log("warm-up done")
@@ -302,6 +305,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         _, objective, _ = tr.train_step(batch)
+    tr.flush()                                   # the last step's parked update (weight gradients, exchange, Adam) is inside the timed region
     sync()
     dt = time.perf_counter() - t0
     prof, ops_lstm.PROFILE = ops_lstm.PROFILE, None
@@ -337,6 +341,7 @@ def main():
         H.PROFILE = []
         for _ in range(NP):
             tr.train_step(batch)
+        tr.flush()
         torch.cuda.synchronize()
         calls, H.PROFILE = H.PROFILE, None
         for name, e0, e1 in calls:
@@ -401,11 +406,14 @@ def main():
         # timed region.  The bf16 trainer's step-persistent workspaces stay allocated (288 GB of HBM: both fit).
         log("timing the fp32 parity mode (1 warm-up + 3 steps)")
         tr32, batch32 = build_trainer("fp32", 0, 1, a.batch, length, a.dirs)
+        tr32.pipeline_update = tr.pipeline_update
         tr32.train_step(batch32)
+        tr32.flush()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             tr32.train_step(batch32)
+        tr32.flush()
         torch.cuda.synchronize()
         ms32 = 1e3 * (time.perf_counter() - t0) / 3
         ops_lstm.check_coop_timeouts("fp32 steps")

@@ -133,6 +133,9 @@ class FSNEngine:
         self._gen = 0                         # train-forward generation: backward must consume the LATEST train forward
         self.last_train = None
         self.grad_range_hook = None           # fn(flat_grad, lo, hi): range final for this step (dp.FlatGradientReducer)
+        self.pre_lstm_hook = None             # one-shot callback run right before this engine's next LSTM launch (trainer)
+        self.defer_join = False               # backward leaves the side-stream join to the caller (join_side)
+        self.join_pending = False
         self.bufs = {}
         own_workspaces(self)                  # step-persistent workspaces keyed by id(self) die with the engine
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
@@ -309,6 +312,12 @@ class FSNEngine:
         # 7: two-layer LSTM over T' steps for the B*F' sequences
         # mtile None: cooperative kernel when the shape allows; it also takes the output head to fuse (bf16 pair kernel)
         head = (self.Whp, self.O) if (FUSED_HEAD > int(train) and prec == H.PREC_BF16 and self.Opad == 16) else None
+        if self.pre_lstm_hook is not None:
+            # everything another stream still has in flight must be joined BEFORE a cooperative (CU-pair) kernel goes out:
+            # its workgroups need the whole chip to themselves.  The trainer parks the previous step's deferred tail
+            # (side-stream weight gradients, gradient exchange, Adam) here: it overlaps this net's small front kernels.
+            hook, self.pre_lstm_hook = self.pre_lstm_hook, None
+            hook()
         lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
@@ -486,7 +495,12 @@ class FSNEngine:
         # (dozens of small kernels that leave most CUs idle); joined at the end of backward.
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            # lowest priority: the dependent chain on the main stream is what the step waits for; the weight-gradient
+            # GEMMs are throughput work (NPPC_SIDE_PRIO=0: default priority, A/B switch)
+            prio = 0
+            if os.environ.get("NPPC_SIDE_PRIO", "1") != "0" and hasattr(torch.cuda.Stream, "priority_range"):
+                prio = max(torch.cuda.Stream.priority_range())
+            self._side = torch.cuda.Stream(device=dev, priority=prio)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq, head=head_wgrad)
@@ -624,5 +638,14 @@ class FSNEngine:
                self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
                self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"), self.g(att + "fc2.bias"),
                B, F, T, self.la, Tp, ldC, s)
-        torch.cuda.current_stream().wait_stream(self._side)       # join the LSTM weight-gradient stream
+        if self.defer_join:
+            self.join_pending = True          # the caller joins (join_side) before anything reads the gradient
+        else:
+            torch.cuda.current_stream().wait_stream(self._side)       # join the weight-gradient stream
         return G
+
+    def join_side(self):
+        """make the current stream wait for the side-stream weight gradients of the last backward (defer_join mode)"""
+        if self.join_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self.join_pending = False

@@ -247,6 +247,13 @@ class NPPCAudioTrainer(nn.Module):
             self.optimizer = getattr(optim, okind)(self.nppc_model.parameters(), **config.optimizer_configuration.args)
         self._flat_adam = None
         self._reducer = FlatGradientReducer()
+        # pipeline_update: the tail of a step (side-stream weight gradients, the rest of the gradient exchange, Adam) is not
+        # waited for at the end of train_step but parked in front of the NEXT step's restorer LSTM launch, so it overlaps
+        # the next minibatch's STFTs and the frozen restorer's full-band front (which do not read the trained weights).
+        # The update is applied before the direction net runs again: results are identical; parameters are current after
+        # flush() (train() flushes at every log interval and at the end, save_checkpoint() always).
+        self.pipeline_update = False
+        self._pending = None
 
     # ---------------------------------------------------------------------------------- reference API
     def base_step(self, batch):
@@ -273,30 +280,49 @@ class NPPCAudioTrainer(nn.Module):
         eng = net.engine()
         # buckets of the flat gradient start their all-reduce from inside backward as soon as they are final (dp.py)
         eng.grad_range_hook = self._reducer.range_ready if (fast and self.world > 1) else None
+        defer = fast and self.pipeline_update
+        eng.defer_join = defer
+        if self._pending is not None:
+            # the previous step's update goes out right before the restorer's LSTM launch of THIS step
+            self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = self.flush
         try:
             reconst_err, objective, log = self.base_step(batch)
+            self.flush()                                     # (no-op when the hook already ran)
             self.optimizer.zero_grad()
             objective.backward()
         finally:
             net.flat_grad_only = False
             eng.grad_range_hook = None
+            eng.defer_join = False
         if fast:
-            gflat = eng.fp.grad
-            scale = self._reducer.finish(gflat)              # sum over ranks; the mean's 1/W goes into Adam's grad scale
-            if self._flat_adam is None or self._flat_adam.eng is not eng:
-                self._flat_adam = FlatAdamStepper(self.optimizer, eng)
-            self._flat_adam.step(gflat, scale)
+            self._pending = eng
+            if not defer:
+                self.flush()
         else:
             mean_reduce_parameter_grads(net.parameters())
             self.optimizer.step()
         self.step += 1
         return reconst_err, objective, log
 
+    def flush(self):
+        """apply a parked update now: join the weight-gradient stream, finish the gradient exchange, one Adam launch"""
+        eng, self._pending = self._pending, None
+        self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = None
+        if eng is None:
+            return
+        eng.join_side()
+        gflat = eng.fp.grad
+        scale = self._reducer.finish(gflat)                  # sum over ranks; the mean's 1/W goes into Adam's grad scale
+        if self._flat_adam is None or self._flat_adam.eng is not eng:
+            self._flat_adam = FlatAdamStepper(self.optimizer, eng)
+        self._flat_adam.step(gflat, scale)
+
     def train(self, n_steps=None, n_epochs=None, checkpoint_dir="checkpoints", log_every=None):
         os.makedirs(checkpoint_dir, exist_ok=True)
         loop_loader = LoopLoader(dataloader=self.dataloader, n_steps=n_steps, n_epochs=n_epochs)
         log_every = log_every or self.config.log_interval
         log_dict = None
+        self.pipeline_update = self.world > 1      # hides the tail of the gradient exchange behind the next step's front
         for it, batch in enumerate(loop_loader):
             if isinstance(batch, (tuple, list)):
                 batch = tuple(x.to(self.device, non_blocking=True) for x in batch)
@@ -312,6 +338,8 @@ class NPPCAudioTrainer(nn.Module):
                 print(f'step {self.step}: Objective: {objective.item():.4f} | '
                       f'Second Moment MSE: {log_dict["second_moment_mse"].mean().item():.4f} | '
                       f'Reconstract Error: {reconst_err.mean().item():.4f}')
+        self.flush()
+        self.pipeline_update = False
         timestamp = datetime.now().strftime("%Y%m%d_%H%M%S")
         if self.rank == 0 and log_dict is not None:
             self._get_and_save_metrics(checkpoint_dir, log_dict, n_epochs, n_steps, timestamp)
@@ -336,6 +364,7 @@ class NPPCAudioTrainer(nn.Module):
 
     def save_checkpoint(self, checkpoint_path):
         """trainer.py:319-335: {'model_state_dict', 'optimizer_state_dict', 'step'}"""
+        self.flush()
         checkpoint = {
             'model_state_dict': self.nppc_model.state_dict(),
             'optimizer_state_dict': self.optimizer.state_dict(),

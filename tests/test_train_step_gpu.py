@@ -287,3 +287,45 @@ def test_training_loop_reduces_the_objective(tmp_path):
     assert all(np.isfinite(objs)) and tr.step == 30
     assert objs[-1] < objs[0] - 0.02, objs[::5]
     assert float(log["reconst_err"].mean()) < 1.0
+
+
+def test_pipelined_update_equals_immediate_update(tmp_path):
+    """pipeline_update parks a step's tail (side-stream weight gradients, gradient exchange, Adam) in front of the NEXT
+    step's restorer LSTM launch: same kernels on the same data, so the objectives along the way are identical and the
+    weights after three steps (+ flush) agree to the run-to-run noise of the fp32 atomics in a few gradient reductions
+    (Adam normalises the gradient: 1e-7 relative gradient noise is ~1e-11 in a weight)"""
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    z, meta = load("g2_k5")
+    c = meta["config"]
+    out = {}
+    for mode in (False, True):
+        model, wts = build_model(c, "bf16", str(tmp_path))
+        cfg = NPPCAudioTrainerConfig(
+            nppc_model_configuration=model.config, data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+            data_loader_configuration=dict(batch_size=c["B"], num_workers=0, pin_memory=False, shuffle=False),
+            optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
+            device="cuda")
+        noisy, clean = (torch.from_numpy(a) for a in waves(z, meta))
+        tr = NPPCAudioTrainer(cfg, dataset=_Mem(noisy, clean))
+        tr.nppc_model.load_state_dict(wts, strict=True)
+        tr.nppc_model.to("cuda")
+        tr.pipeline_update = mode
+        tr.step = 500
+        objs = []
+        for _ in range(3):
+            _, obj, _ = tr.train_step((noisy.cuda(), clean.cuda()))
+            objs.append(obj)
+        if mode:
+            assert tr._pending is not None           # the third update is still parked
+        tr.flush()
+        torch.cuda.synchronize()
+        assert tr._pending is None
+        out[mode] = ([float(o) for o in objs], {k: v.detach().clone() for k, v in tr.nppc_model.audio_pc_wrapper.state_dict().items()})
+        del tr, model
+    assert out[False][0] == out[True][0]
+    for k, v in out[False][1].items():
+        assert float((v.float() - out[True][1][k].float()).abs().max()) < 1e-7, k
+    w0 = {k: v for k, v in wts.items() if k.startswith("audio_pc_wrapper.")}
+    moved = max(float((out[True][1][k[len("audio_pc_wrapper."):]].cpu() - v).abs().max()) for k, v in w0.items())
+    assert moved > 1e-4                       # three Adam steps of lr 1e-4 really happened
+    assert out[True][0][2] < out[True][0][0]
