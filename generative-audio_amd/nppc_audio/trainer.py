@@ -307,9 +307,9 @@ class NPPCAudioTrainer(nn.Module):
     def flush(self):
         """apply a parked update now: join the weight-gradient stream, finish the gradient exchange, one Adam launch"""
         eng, self._pending = self._pending, None
-        self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = None
         if eng is None:
             return
+        self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = None
         eng.join_side()
         gflat = eng.fp.grad
         scale = self._reducer.finish(gflat)                  # sum over ranks; the mean's 1/W goes into Adam's grad scale
