@@ -923,20 +923,46 @@ namespace {
 // no staging registers, no ds_write pass) into a ring of DR_STAGES stages of DR_BR K-rows, DR_STAGES - 1 stages ahead of the
 // MFMAs; a stage is retired with a COUNTED s_waitcnt vmcnt (never 0 in the loop) and ONE raw s_barrier (a __syncthreads()
 // would drain the whole ring: hipcc emits vmcnt(0) in front of it while an LDS-DMA is in flight).
-// LDS image of a stage: A rows [DR_BR][256] bf16 (512 B) then B rows [DR_BR][128] (256 B), each row linear but with its 32-byte
-// chunks XOR-swizzled by key(row) = (row & 3) | ((row >> 3) & 1) << 2: the 8 rows a 32-lane half of ds_read_b64_tr_b16
-// touches then sit on 8 different 32-byte bank groups (un-swizzled they all hit the same 8 banks).  The DMA writes LDS
-// lane-linearly, so the swizzle is applied to each lane's SOURCE address (cdna_hip_programming.md, LDS-DMA caveat).
-constexpr int DR_BM = 256, DR_BN = 128, DR_BR = 64, DR_STAGES = 3;
-constexpr int DR_KS = DR_BR / 32;                        // 32-deep MFMA k-steps per stage
-constexpr int DR_NA = DR_BR * DR_BM * 2 / 1024 / 8, DR_NB = DR_BR * DR_BN * 2 / 1024 / 8;   // 1 KB DMA pieces per wave and stage
-constexpr int DR_A_BYTES = DR_BR * DR_BM * 2, DR_B_BYTES = DR_BR * DR_BN * 2, DR_STAGE_BYTES = DR_A_BYTES + DR_B_BYTES;
+// LDS image of a stage: A rows [BR][256] bf16 (512 B) then B rows [BR][BN], each row linear but with its 32-byte chunks
+// rotated by a per-row key (dr_key below): the 8 rows a 32-lane half of ds_read_b64_tr_b16 touches then sit on 8 different
+// 32-byte bank groups (un-swizzled they all hit the same 8 banks).  The DMA writes LDS lane-linearly, so the swizzle is
+// applied to each lane's SOURCE address (cdna_hip_programming.md, LDS-DMA caveat).
+// Two geometries (template): <BN 128, 64-row stages, 3-stage ring> and <BN 192, 32-row stages, 5-stage ring>.  The kernel is
+// bound by bytes in flight per CU / memory latency (~800 TFLOP/s at 87 FLOP per operand byte with ~100 KB in flight), so
+// the 256 x 192 tile (110 FLOP/B; N = 384 = 2 tiles, 6 x 2 x 64 slices = exactly 3 rounds of 256 workgroups) is the one
+// the LSTM weight gradients use.
+constexpr int DR_BM = 256;
 
+// LDS row swizzle: 32-byte chunk c of row r is stored at chunk (c + key(r)) mod (row bytes / 32), key(r) = (r & 3) | ((r >> 3) & 1) << 2:
+// the 8 rows one 32-lane half of ds_read_b64_tr_b16 touches (r0 .. r0+3 and r0+8 .. r0+11) get 8 different keys -> 8 different
+// 32-byte bank groups (a rotation, not an XOR, so that it also works for the 12-chunk rows of the 192-column tile)
 __device__ __forceinline__ int dr_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ int dr_phys(int bytes_in_row, int key, int nch) {      // logical byte offset -> stored byte offset
+  const int c = bytes_in_row >> 5;
+  int pc = c + key;
+  if (pc >= nch) pc -= nch;
+  return (pc << 5) | (bytes_in_row & 31);
+}
+__device__ __forceinline__ int dr_logical(int bytes_in_row, int key, int nch) {   // stored byte offset -> logical byte offset
+  const int pc = bytes_in_row >> 5;
+  int c = pc - key;
+  if (c < 0) c += nch;
+  return (c << 5) | (bytes_in_row & 31);
+}
 
+template <int BN, int BR, int STAGES>
 __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                              long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
                                                              int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum) {
+  constexpr int KS = BR / 32;                                   // 32-deep MFMA k-steps per stage
+  constexpr int A_BYTES = BR * DR_BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 1024 / 8;                        // whole 1 KB DMA pieces per wave and stage (A)
+  constexpr int BW = B_BYTES / 8;                               // B bytes per wave and stage: NBF whole pieces + one half piece
+  constexpr int NBF = BW / 1024, NBH = (BW % 1024) / 512;
+  static_assert(A_BYTES % 8192 == 0 && BW % 512 == 0 && NBH <= 1, "DMA pieces must divide evenly over the 8 waves");
+  constexpr int NDMA = NA + NBF + NBH;                          // DMA instructions per wave and stage (the vmcnt unit)
+  constexpr int NJ = BN / 32;                                   // 16-column tiles per wave (2 waves across N)
+  constexpr int ACH = DR_BM * 2 / 32, BCH = BN * 2 / 32;        // 32-byte chunks per row
   extern __shared__ __attribute__((aligned(1024))) unsigned char dr_lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
@@ -957,32 +983,34 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   A += (size_t)bb * bsA;
   B += (size_t)bb * bsB;
   C += (size_t)bb * bsC;
-  const long m0 = (long)bx * DR_BM, n0 = (long)by * DR_BN;
+  const long m0 = (long)bx * DR_BM, n0 = (long)by * BN;
   const long rbase = (long)bz * Rz;
   float* Cz = C + (size_t)bz * slab_stride;
 
-  // ---- this wave's DMA pieces of a stage (1 KB each): A pieces DR_NA * w + h (2 rows of 512 B each), B pieces DR_NB * w + h
-  // (4 rows of 256 B each)
-  const unsigned char* srcA[DR_NA];
-  const unsigned char* srcB[DR_NB];
+  // ---- this wave's DMA pieces of a stage.  A: pieces NA*w + h, 1 KB = 2 rows of 512 B.  B: bytes [w*BW, (w+1)*BW) of the
+  // stage's B image (rows of BN*2 bytes back to back): NBF whole pieces and, if BW is not a multiple of 1 KB, one half piece
+  // issued by lanes 0-31 only (the LDS destination of a lane is piece base + 16 * lane, masked lanes write nothing)
+  const unsigned char* srcA[NA];
+  const unsigned char* srcB[NBF + NBH];
 #pragma unroll
-  for (int h = 0; h < DR_NA; ++h) {
-    const int row = 2 * (DR_NA * wave + h) + (lane >> 5);
-    const int p = ((lane & 31) * 16) ^ (dr_key(row) << 5);
+  for (int h = 0; h < NA; ++h) {
+    const int row = 2 * (NA * wave + h) + (lane >> 5);
+    const int p = dr_logical((lane & 31) * 16, dr_key(row), ACH);
     srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbase + row) * lda + m0) + p;
   }
 #pragma unroll
-  for (int h = 0; h < DR_NB; ++h) {
-    const int row = 4 * (DR_NB * wave + h) + (lane >> 4);
-    const int p = ((lane & 15) * 16) ^ (dr_key(row) << 5);
+  for (int h = 0; h < NBF + NBH; ++h) {
+    const int o = wave * BW + h * 1024 + lane * 16;             // byte offset inside the stage's B image
+    const int row = o / (BN * 2);
+    const int p = dr_logical(o % (BN * 2), dr_key(row), BCH);
     srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbase + row) * ldb + n0) + p;
   }
-  const long strA = (long)DR_BR * lda * 2, strB = (long)DR_BR * ldb * 2;        // bytes per stage
-  // The three DMAs of a stage go out through inline asm: issued with the builtin, hipcc treats every later ds_read as a
-  // possible reader of the pending LDS write and puts s_waitcnt vmcnt(0) in front of each stage's first fragment read, which
-  // drains the ring (the stage issued a moment earlier included) -- the pipeline this kernel exists for.  Hidden from the
-  // compiler, their completion is counted by hand below (cdna_hip_programming.md section 5.7 item 1: an LDS-DMA has no
-  // VGPR destination, so it is register-safe).  M0 carries the wave-uniform LDS byte address of each 1 KB piece.
+  const long strA = (long)BR * lda * 2, strB = (long)BR * ldb * 2;        // bytes per stage
+  // The DMAs go out through inline asm: issued with the builtin, hipcc treats every later ds_read as a possible reader of
+  // the pending LDS write and puts s_waitcnt vmcnt(0) in front of each stage's first fragment read, which drains the ring
+  // (the stage issued a moment earlier included) -- the pipeline this kernel exists for.  Hidden from the compiler, their
+  // completion is counted by hand below (cdna_hip_programming.md section 5.7 item 1: an LDS-DMA has no VGPR destination,
+  // so it is register-safe).  M0 carries the wave-uniform LDS byte address of each piece.
   const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)dr_lds;
   auto dma = [&](const unsigned char* src, unsigned ldst) {
     unsigned keep;
@@ -990,34 +1018,37 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
                  : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
   };
   auto fill = [&](int slot, long st) {
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * DR_STAGE_BYTES);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
 #pragma unroll
-    for (int h = 0; h < DR_NA; ++h) dma(srcA[h] + st * strA, l + (DR_NA * wave + h) * 1024);
+    for (int h = 0; h < NA; ++h) dma(srcA[h] + st * strA, l + (NA * wave + h) * 1024);
 #pragma unroll
-    for (int h = 0; h < DR_NB; ++h) dma(srcB[h] + st * strB, l + DR_A_BYTES + (DR_NB * wave + h) * 1024);
+    for (int h = 0; h < NBF; ++h) dma(srcB[h] + st * strB, l + A_BYTES + wave * BW + h * 1024);
+    if (NBH) {
+      if (lane < 32) dma(srcB[NBF] + st * strB, l + A_BYTES + wave * BW + NBF * 1024);
+    }
   };
-  // transposed fragment of k-rows [8 qq, 8 qq + 8) x 16 columns starting at col0 (ds_read_b64_tr_b16, two 4-row halves)
+  // transposed fragment of k-rows [32 ks + 8 qq, + 8) x 16 columns starting at col0 (ds_read_b64_tr_b16, two 4-row halves)
   const int q4 = i16 >> 2, p4 = i16 & 3;
-  auto tfrag = [&](const unsigned char* tile, int rowbytes, int ks, int col0) -> bf16x8 {
+  auto tfrag = [&](const unsigned char* tile, int rowbytes, int nch, int ks, int col0) -> bf16x8 {
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int r_lo = 32 * ks + 8 * qq + q4, r_hi = r_lo + 4;
     const int cb = col0 * 2 + 8 * p4;
-    const unsigned char* lo_p = tile + r_lo * rowbytes + (cb ^ (dr_key(r_lo) << 5));
-    const unsigned char* hi_p = tile + r_hi * rowbytes + (cb ^ (dr_key(r_hi) << 5));
+    const unsigned char* lo_p = tile + r_lo * rowbytes + dr_phys(cb, dr_key(r_lo), nch);
+    const unsigned char* hi_p = tile + r_hi * rowbytes + dr_phys(cb, dr_key(r_hi), nch);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // rowsum (optional): sum_r A[r][m] over the K slice -- the A fragments times an all-ones B fragment, by the waves that
-  // hold column tile 0 (one extra MFMA per four): a bias gradient comes out of the weight-gradient product that reads the
-  // same gate gradients, instead of out of a second pass over them
+  // hold column tile 0 (a few extra MFMAs): a bias gradient comes out of the weight-gradient product that reads the same
+  // gate gradients, instead of out of a second pass over them
   const bool do_rowsum = rowsum != nullptr && by == 0 && wn == 0;
   f32x4 racc[4];
 #pragma unroll
@@ -1025,51 +1056,54 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   typedef __attribute__((ext_vector_type(8))) short ones_t;
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
-  const long nstage = Rz / DR_BR;
+  const long nstage = Rz / BR;
 #pragma unroll
-  for (int s0 = 0; s0 < DR_STAGES - 1; ++s0)
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
     if (s0 < nstage) fill(s0, s0);
   int slot = 0;
   for (long st = 0; st < nstage; ++st) {
-    // stage st has landed once at most the (DR_NA + DR_NB) * (stages issued after it) youngest DMAs of this wave are outstanding
-    static_assert(DR_STAGES == 3 && DR_NA + DR_NB == 6, "the counted waits below are written for a 3-stage ring of 6 pieces");
-    if (st + 1 < nstage) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // stage st has landed once at most NDMA * (stages issued after it) of this wave's youngest DMAs are outstanding
+    const long younger = nstage - 1 - st < STAGES - 2 ? nstage - 1 - st : STAGES - 2;
+    static_assert(STAGES <= 5, "the counted waits below cover rings of up to 5 stages");
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");      // every wave's pieces of stage st landed; everyone is done reading stage st - 1
-    if (st + DR_STAGES - 1 < nstage) {
+    if (st + STAGES - 1 < nstage) {
       int fs = slot - 1;
-      if (fs < 0) fs += DR_STAGES;
-      fill(fs, st + DR_STAGES - 1);             // into the slot stage st - 1 occupied
+      if (fs < 0) fs += STAGES;
+      fill(fs, st + STAGES - 1);                // into the slot stage st - 1 occupied
     }
-    const unsigned char* ta = dr_lds + (size_t)slot * DR_STAGE_BYTES;
-    const unsigned char* tb = ta + DR_A_BYTES;
+    const unsigned char* ta = dr_lds + (size_t)slot * STAGE_BYTES;
+    const unsigned char* tb = ta + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < DR_KS; ++ks) {
-      bf16x8 af[4], bfr[4];
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = tfrag(ta, DR_BM * 2, ks, wm * 64 + 16 * i);
+      for (int i = 0; i < 4; ++i) af[i] = tfrag(ta, DR_BM * 2, ACH, ks, wm * 64 + 16 * i);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = tfrag(tb, DR_BN * 2, ks, wn * 64 + 16 * j);
+      for (int j = 0; j < NJ; ++j) bfr[j] = tfrag(tb, BN * 2, BCH, ks, wn * (BN / 2) + 16 * j);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
       if (do_rowsum) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) racc[i] = mma16(af[i], ones, racc[i]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are complete before it can reach the next barrier
-    slot = slot + 1 == DR_STAGES ? 0 : slot + 1;
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + 16 * i + 4 * qq + r;
-        const long col = n0 + wn * 64 + 16 * j + i16;
+        const long col = n0 + wn * (BN / 2) + 16 * j + i16;
         Cz[row * ldc + col] = acc[i][j][r];
       }
   if (do_rowsum && i16 == 0) {                      // every column of racc holds the row sum: lane column 0 stores it
@@ -1105,28 +1139,54 @@ static bool tn_dma() {
   return v == 1;
 }
 
+// NPPC_TN_DMA192=0: 256 x 128 tiles only (A/B switch)
+static bool tn_dma192() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NPPC_TN_DMA192");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R, int ksplit,
                      int ntap, int Wp, int shift_a, void* stream, int batch = 1, long sA = 0, long sB = 0, long sC = 0,
                      float* rowsum = nullptr) {
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  // LDS-DMA ring kernel: plain (ntap == 1) products with 256 x 128 tiles and 32-row stages, enough workgroups to fill the chip
-  if (ntap == 1 && tn_dma() && M % DR_BM == 0 && N % DR_BN == 0 && (R / ksplit) % DR_BR == 0 &&
-      (long)(M / DR_BM) * (N / DR_BN) * ksplit * batch >= 256) {
-    static bool attr = false;
-    constexpr int smem = DR_STAGES * DR_STAGE_BYTES;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-          hipSuccess)
-        return NPPC_ELAUNCH;
-      attr = true;
+  // LDS-DMA ring kernel: plain (ntap == 1) products, 256 x 192 tiles (32-row stages x 5) when N is a multiple of 192, else
+  // 256 x 128 tiles (64-row stages x 3), as long as there are enough workgroups to fill the chip
+  if (ntap == 1 && tn_dma() && M % DR_BM == 0 && (R / ksplit) % 64 == 0) {
+    const int bn = (N % 192 == 0 && tn_dma192()) ? 192 : (N % 128 == 0 ? 128 : 0);
+    if (bn && (long)(M / DR_BM) * (N / bn) * ksplit * batch >= 256) {
+      dim3 grid(M / DR_BM, N / bn, ksplit * batch);
+      if (bn == 192) {
+        constexpr int smem = 5 * (32 * DR_BM * 2 + 32 * 192 * 2);
+        static bool attr = false;
+        if (!attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel<192, 32, 5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return NPPC_ELAUNCH;
+          attr = true;
+        }
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<192, 32, 5>), grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+                           ldc, (long)M * ldc, R / ksplit, ksplit, sA, sB, sC, rowsum);
+      } else {
+        constexpr int smem = 3 * (64 * DR_BM * 2 + 64 * 128 * 2);
+        static bool attr = false;
+        if (!attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma_kernel<128, 64, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return NPPC_ELAUNCH;
+          attr = true;
+        }
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 64, 3>), grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
+                           ldc, (long)M * ldc, R / ksplit, ksplit, sA, sB, sC, rowsum);
+      }
+      NPPC_CHECK_LAUNCH();
+      return NPPC_OK;
     }
-    dim3 grid(M / DR_BM, N / DR_BN, ksplit * batch);
-    hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, (long)M * ldc,
-                       R / ksplit, ksplit, sA, sB, sC, rowsum);
-    NPPC_CHECK_LAUNCH();
-    return NPPC_OK;
   }
   if (rowsum) return NPPC_EUNSUPPORTED;            // only the LDS-DMA kernel produces row sums
   // 256-row tiles (+4...11 % at these shapes) only when they still give every CU a few workgroups

@@ -20,7 +20,7 @@ def run(M, N, R, S, reps=5):
     ms = e0.elapsed_time(e1) / reps
     print(f"M={M} N={N} R={R} S={S}: {ms:.3f} ms  {2.0*M*N*R/ms/1e9:.0f} TFLOP/s  operands {(M+N)*R*2/1e9:.2f} GB -> {(M+N)*R*2/ms/1e6:.0f} GB/s min", flush=True)
 
-for S in (16, 32, 64):
+for S in (32, 64):
     run(1536, 384, 253 * 4096, S)
 run(1536, 384, 16 * 4096, 16)
 run(1536, 384, 16 * 4096, 64)

@@ -3,9 +3,9 @@
 # C5 / C3 bench lines.  Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=$1
+tag=$1; sel=${2:-tests}
 cd $R && mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/${tag}_gpu_tests.log 2>&1; rc=$?
+python -m pytest $sel -m gpu -x -q --durations=8 > gpurun_out/${tag}_gpu_tests.log 2>&1; rc=$?
 tail -n 14 gpurun_out/${tag}_gpu_tests.log
 [ $rc -eq 0 ] || exit $rc
 bash tools/diag/r02_profile.sh $tag pmc || exit 1
