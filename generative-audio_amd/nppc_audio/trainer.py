@@ -5,7 +5,8 @@
   _get_true_and_pred_crm                              trainer.py:40-371
 
 What differs, deliberately:
-  * every tensor op of the step is a HIP kernel of libnppc_hip.so (no ATen compute on the path);
+  * every tensor op of the step that touches a map, an activation or a weight is a HIP kernel of libnppc_hip.so (what is
+    left to torch is scalar assembly: the mean + lambda * mean of two small loss vectors);
   * the frozen restorer and the noisy STFT run once per step (the reference repeats them 2x / 3x with identical
     results, SURVEY section 0);
   * data parallelism (the reference has none): one process per GPU, contiguous equal shards of the minibatch,
