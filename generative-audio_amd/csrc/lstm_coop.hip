@@ -185,7 +185,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   constexpr int OX0 = 0, OX1 = KX, OH1 = 2 * KX, OH2 = 2 * KX + H;
   constexpr int NKX = KX / 32, NKH = H / 32;
   constexpr int nk1 = NKX + NKH, nk2 = 2 * NKH;
-  constexpr int DEPTH = (MT <= 2 || G == 4) ? 4 : 2;              // weight-fragment ring depth the register budget allows
+  constexpr int DEPTH = (MT <= 2 || G >= 4) ? 4 : 2;              // weight-fragment ring depth the register budget allows
   constexpr int SLICE = MC * HC;                                  // elements of one CU's h slice
   constexpr int SLICE_CH = SLICE * (int)sizeof(T) / 16;           // 16-byte chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1290,11 +1290,16 @@ int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, i
   // candidates (G, mtile): the weight stream per CU shrinks with G, the rows per cluster grow with mtile.  Take the one
   // that occupies the most CUs (all workgroups of a launch must be resident: clusters * G <= n_cu); ties go to the
   // earlier entry (measured at N = 4096: G = 2 beats G = 4, whose 6 waves leave two SIMDs idle).
-  const int cand[4][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 5}};
+  const int cand[6][2] = {{2, 2}, {4, 2}, {4, 4}, {2, 5}, {8, 2}, {8, 5}};
   long best = 0;
-  for (int oi = 0; oi < 4; ++oi) {
+  // eight-CU clusters are built and tested but NOT planned by default: measured at BASELINE C5 they lose to four-CU clusters
+  // (restorer, 2056 sequences: 87.5 vs 48.2 ms; direction net, 1024: 41.8 vs 33.1 ms) -- the seven-partner hand-off costs
+  // more than the halved weight stream saves, as the four-CU clusters already do against CU pairs at C2.  NPPC_LSTM_G8=1 plans them.
+  static const bool g8 = [] { const char* e = getenv("NPPC_LSTM_G8"); return e && e[0] == '1'; }();
+  for (int oi = 0; oi < 6; ++oi) {
     const int g = cand[oi][0], mt = cand[oi][1];
     if (train && mt == 5) continue;
+    if (g == 8 && !g8) continue;
     const long cl = (N + 16 * mt - 1) / (16 * mt);
     if (cl * g <= n_cu && cl * g > best) { best = cl * g; *G = g; *mtile = mt; *clusters = (int)cl; }
   }
@@ -1306,13 +1311,21 @@ static int fwd_coop_impl(int prec, int train, int G, int mtile, const void* x, c
                          const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
                          void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
                          float* hpart, int O, void* stream) {
-  if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4)) return NPPC_EUNSUPPORTED;
+  if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4 && G != 8)) return NPPC_EUNSUPPORTED;
   if (!x || !wp1 || !wp2 || (!h2 && (!whp || train)) || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
   if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
   if (whp && (G != 2 || !hpart || O < 1 || O > 16)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
   CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC), whp, hpart, O};
   hipStream_t s = (hipStream_t)stream;
+  if (G == 8) {
+    // eight CUs per cluster (48 hidden units = 3 waves each, 1/8 of the weight stream per CU): for the few long sequences
+    // of the long-clip configuration (BASELINE C5: 1024 / 2056 sequences would leave half the chip idle with G <= 4)
+    if (mtile == 2)
+      return train ? launch_coop<bf16_t, 8, 2, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 8, 2, false>(a, (size_t)xch_bytes, s);
+    if (mtile == 5 && !train) return launch_coop<bf16_t, 8, 5, false>(a, (size_t)xch_bytes, s);
+    return NPPC_EUNSUPPORTED;
+  }
   if (G == 4) {
     if (mtile == 4)
       return train ? launch_coop<bf16_t, 4, 4, true>(a, (size_t)xch_bytes, s) : launch_coop<bf16_t, 4, 4, false>(a, (size_t)xch_bytes, s);

@@ -111,6 +111,11 @@ def unfold_multiplicity(F, nb):
 
 
 class FSNEngine:
+    # engines whose side-stream weight gradients have not been joined yet (defer_join mode).  A cooperative (CU-pair) LSTM
+    # kernel needs every CU for its own workgroups, so NOTHING of ours may be in flight on another stream when one is
+    # launched: forward / backward refuse to launch while this set is non-empty (the trainer's pre_lstm_hook empties it).
+    _unjoined = set()
+
     def __init__(self, flat, *, num_freqs, n_maps, out_size, sb_neighbors, look_ahead, sb_hidden, groups, kersize,
                  prec, trainable):
         self.fp = flat
@@ -138,6 +143,8 @@ class FSNEngine:
         self.join_pending = False
         self.bufs = {}
         own_workspaces(self)                  # step-persistent workspaces keyed by id(self) die with the engine
+        import weakref
+        weakref.finalize(self, FSNEngine._unjoined.discard, id(self))
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
         self.KX = self.lstm.kx
         self.mult = torch.from_numpy(unfold_multiplicity(self.F, self.nb)).to(self.dev)
@@ -318,6 +325,9 @@ class FSNEngine:
             # (side-stream weight gradients, gradient exchange, Adam) here: it overlaps this net's small front kernels.
             hook, self.pre_lstm_hook = self.pre_lstm_hook, None
             hook()
+        if FSNEngine._unjoined:
+            raise RuntimeError("side-stream weight gradients of a previous backward are still in flight (defer_join): join "
+                               "them (NPPCAudioTrainer.flush / FSNEngine.join_side) before the next LSTM launch")
         lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
@@ -640,6 +650,7 @@ class FSNEngine:
                B, F, T, self.la, Tp, ldC, s)
         if self.defer_join:
             self.join_pending = True          # the caller joins (join_side) before anything reads the gradient
+            FSNEngine._unjoined.add(id(self))
         else:
             torch.cuda.current_stream().wait_stream(self._side)       # join the weight-gradient stream
         return G
@@ -649,3 +660,4 @@ class FSNEngine:
         if self.join_pending:
             torch.cuda.current_stream().wait_stream(self._side)
             self.join_pending = False
+            FSNEngine._unjoined.discard(id(self))

@@ -149,7 +149,8 @@ def test_lstm_bwd_matches_autograd(Hd, I, prec, tol):
 
 @pytest.mark.parametrize("N,Tn,train,force", [(50, 23, False, (2, 2)), (50, 23, True, (2, 2)), (200, 9, False, (2, 5)),
                                               (512, 7, True, (4, 4)), (100, 11, False, (4, 4)), (777, 5, True, (2, 2)),
-                                              (300, 9, True, (4, 2)), (90, 13, False, (4, 2))])
+                                              (300, 9, True, (4, 2)), (90, 13, False, (4, 2)),
+                                              (100, 11, False, (8, 2)), (300, 9, True, (8, 2)), (200, 7, False, (8, 5))])
 def test_cooperative_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train, force):
     """The CU-pair kernel (weights split over two workgroups, h slices exchanged through global memory) must give
     the same numbers as the single-workgroup kernel, and no bounded spin may time out."""
