@@ -276,9 +276,14 @@ def main():
     workload = {(BATCH, SECONDS, K_DIRS): "C2", (8, 30, 8): "C5"}.get((a.batch, a.seconds, a.dirs), "custom")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call: dmabuf IPC for RCCL
+    backend = os.environ.get("NPPC_DP_BACKEND", "nccl")           # "gloo": rehearsal of the N > 1 control flow on a 1-GPU box
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
 
     from nppc_audio import _hip as H
     from nppc_audio import ops_lstm
@@ -336,7 +341,7 @@ def main():
 
     # ---- untimed pass with HIP events around EVERY launch: ranks the kernels, times the HBM-bound families -------
     totals, fam = {}, None
-    if not a.no_families:
+    if world == 1 and not a.no_families:          # (N > 1: the other ranks have left; more steps would wait for them forever)
         NP = 3
         H.PROFILE = []
         for _ in range(NP):

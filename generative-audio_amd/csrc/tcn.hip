@@ -953,7 +953,8 @@ __device__ __forceinline__ int dr_logical(int bytes_in_row, int key, int nch) { 
 template <int BN, int BR, int STAGES>
 __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                              long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
-                                                             int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum) {
+                                                             int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum,
+                                                             int ntap, int Wp, int shift_a) {
   constexpr int KS = BR / 32;                                   // 32-deep MFMA k-steps per stage
   constexpr int A_BYTES = BR * DR_BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int NA = A_BYTES / 1024 / 8;                        // whole 1 KB DMA pieces per wave and stage (A)
@@ -984,7 +985,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   B += (size_t)bb * bsB;
   C += (size_t)bb * bsC;
   const long m0 = (long)bx * DR_BM, n0 = (long)by * BN;
-  const long rbase = (long)bz * Rz;
+  // bz = tap * ksplit + slice (ntap == 9: the nine row-shifted products of a 3x3 convolution weight gradient, see
+  // gemm_tn_tiled_kernel; the operands carry guard rows for the negative shifts)
+  const int ksl = nzb / ntap, tap = bz / ksl;
+  const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
+  const long rbase = (long)(bz % ksl) * Rz;
+  const long rbaseA = rbase + (shift_a ? boff : 0), rbaseB = rbase + (shift_a ? 0 : boff);
   float* Cz = C + (size_t)bz * slab_stride;
 
   // ---- this wave's DMA pieces of a stage.  A: pieces NA*w + h, 1 KB = 2 rows of 512 B.  B: bytes [w*BW, (w+1)*BW) of the
@@ -996,14 +1002,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   for (int h = 0; h < NA; ++h) {
     const int row = 2 * (NA * wave + h) + (lane >> 5);
     const int p = dr_logical((lane & 31) * 16, dr_key(row), ACH);
-    srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbase + row) * lda + m0) + p;
+    srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbaseA + row) * lda + m0) + p;
   }
 #pragma unroll
   for (int h = 0; h < NBF + NBH; ++h) {
     const int o = wave * BW + h * 1024 + lane * 16;             // byte offset inside the stage's B image
     const int row = o / (BN * 2);
     const int p = dr_logical(o % (BN * 2), dr_key(row), BCH);
-    srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbase + row) * ldb + n0) + p;
+    srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbaseB + row) * ldb + n0) + p;
   }
   const long strA = (long)BR * lda * 2, strB = (long)BR * ldb * 2;        // bytes per stage
   // The DMAs go out through inline asm: issued with the builtin, hipcc treats every later ds_read as a possible reader of
@@ -1155,12 +1161,12 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
   if (!A || !B || !C || M <= 0 || N <= 0 || R <= 0 || ksplit < 1 || (ntap != 1 && ntap != 9)) return NPPC_EBADARG;
   if (M % 128 || N % 64 || R % (64L * ksplit) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  // LDS-DMA ring kernel: plain (ntap == 1) products, 256 x 192 tiles (32-row stages x 5) when N is a multiple of 192, else
+  // LDS-DMA ring kernel (plain products and the nine-tap convolution weight gradient): 256 x 192 tiles (32-row stages x 5) when N is a multiple of 192, else
   // 256 x 128 tiles (64-row stages x 3), as long as there are enough workgroups to fill the chip
-  if (ntap == 1 && tn_dma() && M % DR_BM == 0 && (R / ksplit) % 64 == 0) {
+  if (tn_dma() && M % DR_BM == 0 && (R / ksplit) % 64 == 0 && (ntap == 1 || batch == 1)) {
     const int bn = (N % 192 == 0 && tn_dma192()) ? 192 : (N % 128 == 0 ? 128 : 0);
-    if (bn && (long)(M / DR_BM) * (N / bn) * ksplit * batch >= 256) {
-      dim3 grid(M / DR_BM, N / bn, ksplit * batch);
+    if (bn && (long)(M / DR_BM) * (N / bn) * ksplit * ntap * batch >= 256) {
+      dim3 grid(M / DR_BM, N / bn, ksplit * ntap * batch);
       if (bn == 192) {
         constexpr int smem = 5 * (32 * DR_BM * 2 + 32 * 192 * 2);
         static bool attr = false;
@@ -1171,7 +1177,7 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
           attr = true;
         }
         hipLaunchKernelGGL((gemm_tn_dma_kernel<192, 32, 5>), grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
-                           ldc, (long)M * ldc, R / ksplit, ksplit, sA, sB, sC, rowsum);
+                           ldc, (long)M * ldc, R / ksplit, ksplit * ntap, sA, sB, sC, rowsum, ntap, Wp, shift_a);
       } else {
         constexpr int smem = 3 * (64 * DR_BM * 2 + 64 * 128 * 2);
         static bool attr = false;
@@ -1182,7 +1188,7 @@ static int launch_tn(const void* A, long lda, const void* B, long ldb, float* C,
           attr = true;
         }
         hipLaunchKernelGGL((gemm_tn_dma_kernel<128, 64, 3>), grid, dim3(512), smem, s, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C,
-                           ldc, (long)M * ldc, R / ksplit, ksplit, sA, sB, sC, rowsum);
+                           ldc, (long)M * ldc, R / ksplit, ksplit * ntap, sA, sB, sC, rowsum, ntap, Wp, shift_a);
       }
       NPPC_CHECK_LAUNCH();
       return NPPC_OK;
