@@ -1257,6 +1257,26 @@ __global__ void lstm_coop_pack_bwd2_kernel(const float* __restrict__ w_ih, const
   }
 }
 
+// All workgroups of a cooperative launch must be resident at once (partners spin on each other's flags).  The launchers
+// size the grid to at most one workgroup per CU and request more than half a CU's LDS; this asks the runtime whether the
+// kernel as built (registers, LDS, waves) really fits one workgroup per CU on THIS device and that the grid does not exceed
+// the CU count -- checked at launch, not assumed.  What it cannot see is work of OTHER streams occupying CUs: the engine
+// never has any in flight when it launches one of these kernels (FSNEngine._unjoined, pre_lstm_hook), and a partner that
+// is late only costs time: every spin is bounded and counted (sticky time-out counter).
+static int coop_fits(const void* kernel, int threads, size_t smem, int grid, int& per_cu_cache) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NPPC_ELAUNCH;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return NPPC_ELAUNCH;
+  }
+  if (per_cu_cache < 0 &&                            // per instantiation: the occupancy query is not free
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cache, kernel, threads, smem) != hipSuccess)
+    return NPPC_ELAUNCH;
+  if (per_cu_cache < 1 || grid > n_cu) return NPPC_EUNSUPPORTED;
+  return NPPC_OK;
+}
+
 template <typename T, int G, int MT, bool TRAIN, bool HEAD = false>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
@@ -1274,6 +1294,9 @@ static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   if (hipMemsetAsync(a.flags, 0, (size_t)a.clusters * 2 * G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   // G = 2: grid rounded up to a multiple of 8 for the XCD-aware placement (coop_ids); spare workgroups exit at once
   const int grid = G == 2 ? round_up(a.clusters * G, 8) : a.clusters * G;
+  static int per_cu = -1;
+  const int fits = coop_fits(reinterpret_cast<const void*>(k), (H / G / 16) * 64, smem, a.clusters * G, per_cu);
+  if (fits != NPPC_OK) return fits;
   hipLaunchKernelGGL(k, dim3(grid), dim3((H / G / 16) * 64), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
@@ -1436,6 +1459,9 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)
                       : reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<false>);
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return NPPC_ELAUNCH;
+  static int per_cu[2] = {-1, -1};
+  const int fits = coop_fits(k, CB_NT, smem, clusters * CB_G, per_cu[dyt ? 1 : 0]);
+  if (fits != NPPC_OK) return fits;
   if (hipMemsetAsync(flags, 0, (size_t)clusters * 2 * CB_G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   if (dyt)
     hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<true>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
