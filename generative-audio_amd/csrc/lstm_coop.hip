@@ -54,6 +54,11 @@ struct CoopArgs {
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+#ifdef CF_NO_POLL
+constexpr bool CF_POLL = false;                      // diagnostic: never wait for a partner (timing only, results are garbage)
+#else
+constexpr bool CF_POLL = true;
+#endif
 
 __device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t r, int off, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);   // aux 16 = sc1 (write-through)
@@ -67,6 +72,9 @@ __device__ __forceinline__ u32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t r, int off
 template <typename T>
 __device__ __forceinline__ int frag_boff(int gp, int ublk, int kk, int s, int nk) {
   const int w8 = ublk / 3, ub3 = ublk % 3;
+#ifdef CF_W_L1
+  return (((((gp * 8 + w8) * nk + kk) * 3 + ub3) * 2 + s) * 512 * (int)sizeof(T)) & 0x3fff;   // diagnostic: weights from L1
+#endif
   return ((((gp * 8 + w8) * nk + kk) * 3 + ub3) * 2 + s) * 512 * (int)sizeof(T);
 }
 
@@ -296,7 +304,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     if (wave == 0) {
       if (lane < G && lane != cu) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+        while (CF_POLL && __hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
             __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -328,7 +336,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   auto wave_poll = [&](int layer, int ep) {
     if (lane < G && lane != cu) {
       unsigned spins = 0;
-      while (__hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+      while (CF_POLL && __hip_atomic_load(flags + layer * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > SPIN_LIMIT) {
           __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
     if (wave == 0) {
       if (lane == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+        while (CF_POLL && __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
             __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -846,6 +854,9 @@ constexpr int C2_XW = 2 * CB_HC;                            // 384 partial colum
 
 // B fragment (cu, wave, kk, slot): [cu][wave][kk][slot][lane][8]
 __device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) {
+#ifdef CF_W_L1
+  return (((((cu * CB_NW + wave) * C2_NKK + kk) * C2_SLOTS + slot) * 512) * 2) & 0x3fff;      // diagnostic: weights from L1
+#endif
   return ((((cu * CB_NW + wave) * C2_NKK + kk) * C2_SLOTS + slot) * 512) * 2;
 }
 
@@ -1035,7 +1046,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     if (wave == 0) {
       if (lane == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
+        while (CF_POLL && __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > SPIN_LIMIT) {
             __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
