@@ -936,7 +936,11 @@ constexpr int DR_BM = 256;
 // LDS row swizzle: 32-byte chunk c of row r is stored at chunk (c + key(r)) mod (row bytes / 32), key(r) = (r & 3) | ((r >> 3) & 1) << 2:
 // the 8 rows one 32-lane half of ds_read_b64_tr_b16 touches (r0 .. r0+3 and r0+8 .. r0+11) get 8 different keys -> 8 different
 // 32-byte bank groups (a rotation, not an XOR, so that it also works for the 12-chunk rows of the 192-column tile)
-__device__ __forceinline__ int dr_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+// (rows of fewer than 8 chunks -- the 64-column tile -- keep the low bits only: two rows of a half then share a bank group)
+__device__ __forceinline__ int dr_key(int row, int nch) {
+  const int k = (row & 3) | (((row >> 3) & 1) << 2);
+  return nch >= 8 ? k : (k & (nch - 1));
+}
 __device__ __forceinline__ int dr_phys(int bytes_in_row, int key, int nch) {      // logical byte offset -> stored byte offset
   const int c = bytes_in_row >> 5;
   int pc = c + key;
@@ -950,11 +954,13 @@ __device__ __forceinline__ int dr_logical(int bytes_in_row, int key, int nch) { 
   return (c << 5) | (bytes_in_row & 31);
 }
 
+// One 256 x BN output tile of one K slice: A rows [rbaseA, rbaseA + Rz) x columns [m0, m0 + 256), B rows [rbaseB, ...) x
+// columns [n0, n0 + BN) -> Cz[m0 + ..][c0 + ..] (c0: the tile's first column in the slab, = n0 unless B is one of several
+// sources side by side); `rs` != nullptr: also the row sums of the A tile -> rs[m0 + ..].
 template <int BN, int BR, int STAGES>
-__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
-                                                             long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
-                                                             int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum,
-                                                             int ntap, int Wp, int shift_a) {
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                         float* __restrict__ Cz, long ldc, long m0, long n0, long c0, long rbaseA, long rbaseB,
+                                         long Rz, float* __restrict__ rs) {
   constexpr int KS = BR / 32;                                   // 32-deep MFMA k-steps per stage
   constexpr int A_BYTES = BR * DR_BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int NA = A_BYTES / 1024 / 8;                        // whole 1 KB DMA pieces per wave and stage (A)
@@ -969,29 +975,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (gridDim.z % 8 == 0) {                   // all output tiles of one K slice on ONE XCD (see gemm_tn_tiled_kernel)
-    const unsigned tiles = gridDim.x * gridDim.y;
-    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
-    const unsigned xcd = lin & 7, j = lin >> 3;
-    bz = xcd + 8 * (j / tiles);
-    const unsigned t = j % tiles;
-    bx = t % gridDim.x;
-    by = t / gridDim.x;
-  }
-  const unsigned bb = bz / nzb;
-  bz %= nzb;
-  A += (size_t)bb * bsA;
-  B += (size_t)bb * bsB;
-  C += (size_t)bb * bsC;
-  const long m0 = (long)bx * DR_BM, n0 = (long)by * BN;
-  // bz = tap * ksplit + slice (ntap == 9: the nine row-shifted products of a 3x3 convolution weight gradient, see
-  // gemm_tn_tiled_kernel; the operands carry guard rows for the negative shifts)
-  const int ksl = nzb / ntap, tap = bz / ksl;
-  const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
-  const long rbase = (long)(bz % ksl) * Rz;
-  const long rbaseA = rbase + (shift_a ? boff : 0), rbaseB = rbase + (shift_a ? 0 : boff);
-  float* Cz = C + (size_t)bz * slab_stride;
 
   // ---- this wave's DMA pieces of a stage.  A: pieces NA*w + h, 1 KB = 2 rows of 512 B.  B: bytes [w*BW, (w+1)*BW) of the
   // stage's B image (rows of BN*2 bytes back to back): NBF whole pieces and, if BW is not a multiple of 1 KB, one half piece
@@ -1001,14 +984,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
 #pragma unroll
   for (int h = 0; h < NA; ++h) {
     const int row = 2 * (NA * wave + h) + (lane >> 5);
-    const int p = dr_logical((lane & 31) * 16, dr_key(row), ACH);
+    const int p = dr_logical((lane & 31) * 16, dr_key(row, ACH), ACH);
     srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbaseA + row) * lda + m0) + p;
   }
 #pragma unroll
   for (int h = 0; h < NBF + NBH; ++h) {
     const int o = wave * BW + h * 1024 + lane * 16;             // byte offset inside the stage's B image
     const int row = o / (BN * 2);
-    const int p = dr_logical(o % (BN * 2), dr_key(row), BCH);
+    const int p = dr_logical(o % (BN * 2), dr_key(row, BCH), BCH);
     srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbaseB + row) * ldb + n0) + p;
   }
   const long strA = (long)BR * lda * 2, strB = (long)BR * ldb * 2;        // bytes per stage
@@ -1039,8 +1022,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const int r_lo = 32 * ks + 8 * qq + q4, r_hi = r_lo + 4;
     const int cb = col0 * 2 + 8 * p4;
-    const unsigned char* lo_p = tile + r_lo * rowbytes + dr_phys(cb, dr_key(r_lo), nch);
-    const unsigned char* hi_p = tile + r_hi * rowbytes + dr_phys(cb, dr_key(r_hi), nch);
+    const unsigned char* lo_p = tile + r_lo * rowbytes + dr_phys(cb, dr_key(r_lo, nch), nch);
+    const unsigned char* hi_p = tile + r_hi * rowbytes + dr_phys(cb, dr_key(r_hi, nch), nch);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lo_p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(hi_p));
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1055,7 +1038,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   // rowsum (optional): sum_r A[r][m] over the K slice -- the A fragments times an all-ones B fragment, by the waves that
   // hold column tile 0 (a few extra MFMAs): a bias gradient comes out of the weight-gradient product that reads the same
   // gate gradients, instead of out of a second pass over them
-  const bool do_rowsum = rowsum != nullptr && by == 0 && wn == 0;
+  const bool do_rowsum = rs != nullptr && wn == 0;
   f32x4 racc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1109,16 +1092,74 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + 16 * i + 4 * qq + r;
-        const long col = n0 + wn * (BN / 2) + 16 * j + i16;
+        const long col = c0 + wn * (BN / 2) + 16 * j + i16;
         Cz[row * ldc + col] = acc[i][j][r];
       }
   if (do_rowsum && i16 == 0) {                      // every column of racc holds the row sum: lane column 0 stores it
-    float* rs = rowsum + ((size_t)bb * nzb + bz) * ((size_t)gridDim.x * DR_BM);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) rs[m0 + wm * 64 + 16 * i + 4 * qq + r] = racc[i][r];
   }
+}
+
+// all output tiles of one K slice on ONE XCD (see gemm_tn_tiled_kernel): remaps (bx, by, bz) when gridDim.z % 8 == 0
+__device__ __forceinline__ void dr_xcd_remap(unsigned& bx, unsigned& by, unsigned& bz) {
+  if (gridDim.z % 8 == 0) {
+    const unsigned tiles = gridDim.x * gridDim.y;
+    const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+    const unsigned xcd = lin & 7, j = lin >> 3;
+    bz = xcd + 8 * (j / tiles);
+    const unsigned t = j % tiles;
+    bx = t % gridDim.x;
+    by = t / gridDim.x;
+  }
+}
+
+template <int BN, int BR, int STAGES>
+__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                             long ldb, float* __restrict__ C, long ldc, long slab_stride, long Rz,
+                                                             int nzb, long bsA, long bsB, long bsC, float* __restrict__ rowsum,
+                                                             int ntap, int Wp, int shift_a) {
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  dr_xcd_remap(bx, by, bz);
+  const unsigned bb = bz / nzb;
+  bz %= nzb;
+  A += (size_t)bb * bsA;
+  B += (size_t)bb * bsB;
+  C += (size_t)bb * bsC;
+  // bz = tap * ksplit + slice (ntap == 9: the nine row-shifted products of a 3x3 convolution weight gradient, see
+  // gemm_tn_tiled_kernel; the operands carry guard rows for the negative shifts)
+  const int ksl = nzb / ntap, tap = bz / ksl;
+  const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
+  const long rbase = (long)(bz % ksl) * Rz;
+  float* rs = rowsum != nullptr && by == 0 ? rowsum + ((size_t)bb * nzb + bz) * ((size_t)gridDim.x * DR_BM) : nullptr;
+  dma_tile<BN, BR, STAGES>(A, lda, B, ldb, C + (size_t)bz * slab_stride, ldc, (long)bx * DR_BM, (long)by * BN, (long)by * BN,
+                           rbase + (shift_a ? boff : 0), rbase + (shift_a ? 0 : boff), Rz, rs);
+}
+
+// Two B operands side by side behind ONE pass over A: C[z][m][0 .. N1) = A^T . B1, C[z][m][N1 .. N1 + N2) = A^T . B2.
+// Column tiles 0 .. nt1-1 are 192 wide and read B1; then either N2 / 192 tiles of 192 or (N2 == 64) one 64-wide tile read
+// B2.  All column tiles of a K slice run on one XCD at about the same time, so the A rows come from HBM once and from that
+// XCD's L2 for the other tiles: the LSTM weight gradients that share their gate gradients (W_ih | W_hh of a layer) cost one
+// pass over them instead of two or three.
+template <int BR, int STAGES>
+__global__ __launch_bounds__(512, 1) void gemm_tn_dma2_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B1,
+                                                              long ldb1, int nt1, const bf16_t* __restrict__ B2, long ldb2, int N2,
+                                                              float* __restrict__ C, long ldc, long slab_stride, long Rz,
+                                                              float* __restrict__ rowsum) {
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  dr_xcd_remap(bx, by, bz);
+  const long m0 = (long)bx * DR_BM, rbase = (long)bz * Rz;
+  float* Cz = C + (size_t)bz * slab_stride;
+  float* rs = rowsum != nullptr && by == 0 ? rowsum + (size_t)bz * ((size_t)gridDim.x * DR_BM) : nullptr;
+  if ((int)by >= nt1 && N2 == 64) {
+    dma_tile<64, BR, STAGES>(A, lda, B2, ldb2, Cz, ldc, m0, 0, (long)nt1 * 192, rbase, rbase, Rz, nullptr);
+    return;
+  }
+  const bool second = (int)by >= nt1;
+  const long n0 = (long)(second ? by - nt1 : by) * 192;
+  dma_tile<192, BR, STAGES>(A, lda, second ? B2 : B1, second ? ldb2 : ldb1, Cz, ldc, m0, n0, (long)by * 192, rbase, rbase, Rz, rs);
 }
 
 }  // namespace
@@ -1225,6 +1266,32 @@ extern "C" int nppc_gemm_tn_splitk_rowsum(const void* A, long lda, const void* B
                                           int ksplit, float* rowsum, void* stream) {
   if (!rowsum) return NPPC_EBADARG;
   return launch_tn(A, lda, B, ldb, C, ldc, M, N, R, ksplit, 1, 0, 0, stream, 1, 0, 0, 0, rowsum);
+}
+
+// One pass over A for two B operands side by side (gemm_tn_dma2_kernel): C_slab[z][m][0 .. N1) = A^T . B1 and
+// C_slab[z][m][N1 .. N1 + N2) = A^T . B2 over the rows of slice z; rowsum optional ([ksplit][M], as above).  bf16, M % 256 == 0,
+// N1 % 192 == 0, N2 == 64 or N2 % 192 == 0, (R / ksplit) % 64 == 0, ldc >= N1 + N2; NPPC_EUNSUPPORTED otherwise (the caller
+// then runs the two products separately).
+extern "C" int nppc_gemm_tn_splitk2(const void* A, long lda, const void* B1, long ldb1, int N1, const void* B2, long ldb2, int N2,
+                                    float* C, long ldc, int M, long R, int ksplit, float* rowsum, void* stream) {
+  if (!A || !B1 || !B2 || !C || M <= 0 || N1 <= 0 || N2 <= 0 || R <= 0 || ksplit < 1) return NPPC_EBADARG;
+  if (lda % 8 || ldb1 % 8 || ldb2 % 8 || ldc < N1 + N2) return NPPC_EBADARG;
+  if (!tn_dma() || M % DR_BM || N1 % 192 || (N2 != 64 && N2 % 192) || R % ksplit || (R / ksplit) % 64) return NPPC_EUNSUPPORTED;
+  const int nt1 = N1 / 192, nt2 = N2 == 64 ? 1 : N2 / 192;
+  if ((long)(M / DR_BM) * (nt1 + nt2) * ksplit < 256) return NPPC_EUNSUPPORTED;
+  constexpr int smem = 5 * (32 * DR_BM * 2 + 32 * 192 * 2);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma2_kernel<32, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return NPPC_ELAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_dma2_kernel<32, 5>), dim3(M / DR_BM, nt1 + nt2, ksplit), dim3(512), smem, (hipStream_t)stream,
+                     (const bf16_t*)A, lda, (const bf16_t*)B1, ldb1, nt1, (const bf16_t*)B2, ldb2, N2, C, ldc, (long)M * ldc,
+                     R / ksplit, rowsum);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
 }
 
 // `batch` independent products in one launch (operand / slab strides in elements; slabs of batch b start at C + b*sC)

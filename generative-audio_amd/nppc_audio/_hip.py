@@ -118,6 +118,7 @@ SIGS = {
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],
     "nppc_gemm_tn_splitk": [P, L, P, L, P, L, I, I, L, I, P],
     "nppc_gemm_tn_splitk_rowsum": [P, L, P, L, P, L, I, I, L, I, P, P],
+    "nppc_gemm_tn_splitk2": [P, L, P, L, I, P, L, I, P, L, I, L, I, P, P],
     "nppc_gemm_tn_splitk_batched": [P, L, L, P, L, L, P, L, L, I, I, L, I, I, P],
     "nppc_reduce_slabs_t": [P, I, L, L, P, L, I, I, L, L, I, P],
     "nppc_gemm_tn_splitk_taps": [P, L, P, L, P, L, I, I, L, I, I, I, P],

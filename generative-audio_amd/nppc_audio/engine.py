@@ -27,6 +27,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
+TN_PAIRED = os.environ.get("NPPC_TN_PAIRED", "1") != "0"              # one pass over the gate gradients per LSTM layer (A/B switch)
 FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "3"))    # 0: head kernels; 1: fused in the inference forward; 2: + training forward; 3: + backward
 
 
@@ -376,7 +377,7 @@ class FSNEngine:
         H.call("nppc_reduce_slabs", slab, S, rows * ncolsN, ncolsN, dst, dst_ld, out_rows, col0, ncols, permH, accumulate,
                S * rows * ncolsN, sDst, batch, s)
 
-    def _lstm_wgrad(self, dg1, dg2, x_rows, h1_rows, h2_rows, Tv, Nseq, head=None):
+    def _lstm_wgrad(self, dg1, dg2, x_rows, h1_rows, h2_rows, Tv, Nseq, head=None, guards=None):
         """LSTM weight / bias gradients from the row-major gate gradients (runs on the side stream).
         head = (dyt_rows [Rpad][16] bf16, O): also the output head's weight / bias gradients, as one more TN product
         h2^T . dY (the 16-column dY rows are read as a 64-column operand: the extra columns are ignored)."""
@@ -412,6 +413,29 @@ class FSNEngine:
             # the layer-2 bias gradient (column sums of dg2) comes out of the W_ih_l1 product as row sums of its A operand
             # (LDS-DMA kernel, csrc/tcn.hip) instead of out of a 64-column product of its own that re-read all of dg2
             fold_bias = K4 % 256 == 0 and Hd % 128 == 0 and (K4 // 256) * (Hd // 128) * S >= 256
+            # ONE pass over each layer's gate gradients for both of its weight gradients (`nppc_gemm_tn_splitk2`):
+            #   layer 1: dg1^T . [h1_{t-1} | x_t]   (x's spare column carries the bias gradient)
+            #   layer 2: dg2^T . [h1_t | h2_{t-1}]  (+ row sums of dg2 = the bias gradient)
+            # h_{t-1} is the guard view of the h rows (N zero rows in front), so the gate gradients are not shifted
+            if (guards is not None and TN_PAIRED and fold_bias and Hd % 192 == 0 and KX == 64 and Tv > 1
+                    and (K4 // 256) * (Hd // 192 + 1) * S >= 256):
+                h1_guard, h2_guard = guards
+                rows = (Rr + 64 * S - 1) // (64 * S) * (64 * S)
+                slab = ws("slab2", (S * K4 * 2 * Hd,), torch.float32)
+                rsum = ws("rowsum", (S, K4), torch.float32)
+                H.call("nppc_gemm_tn_splitk2", dg1, K4, h1_guard, Hd, Hd, x_rows, KX, KX, slab, Hd + KX, K4, rows, S, None, s)
+                n1 = K4 * (Hd + KX)
+                H.call("nppc_reduce_slabs", slab, S, n1, Hd + KX, self.g(q + "weight_hh_l0"), Hd, K4, 0, Hd, Hd, 0, 0, 0, 1, s)
+                H.call("nppc_reduce_slabs", slab, S, n1, Hd + KX, self.g(q + "weight_ih_l0"), I, K4, Hd, I, Hd, 0, 0, 0, 1, s)
+                H.call("nppc_reduce_slabs", slab, S, n1, Hd + KX, self.g(q + "bias_ih_l0"), 1, K4, Hd + I, 1, Hd, 0, 0, 0, 1, s)
+                self.g(q + "bias_hh_l0").copy_(self.g(q + "bias_ih_l0"))
+                H.call("nppc_gemm_tn_splitk2", dg2, K4, h1_rows, Hd, Hd, h2_guard, Hd, Hd, slab, 2 * Hd, K4, rows, S, rsum, s)
+                n2 = K4 * 2 * Hd
+                H.call("nppc_reduce_slabs", slab, S, n2, 2 * Hd, self.g(q + "weight_ih_l1"), Hd, K4, 0, Hd, Hd, 0, 0, 0, 1, s)
+                H.call("nppc_reduce_slabs", slab, S, n2, 2 * Hd, self.g(q + "weight_hh_l1"), Hd, K4, Hd, Hd, Hd, 0, 0, 0, 1, s)
+                H.call("nppc_reduce_slabs", rsum, S, K4, 1, self.g(q + "bias_ih_l1"), 1, K4, 0, 1, Hd, 0, 0, 0, 1, s)
+                self.g(q + "bias_hh_l1").copy_(self.g(q + "bias_ih_l1"))
+                jobs = []
             for dg, off, inp, width, dest in jobs:
                 rows = (Rr - off + 64 * S - 1) // (64 * S) * (64 * S)
                 if fold_bias and dest[0] == "bias":
@@ -513,7 +537,8 @@ class FSNEngine:
             self._side = torch.cuda.Stream(device=dev, priority=prio)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq, head=head_wgrad)
+            self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq, head=head_wgrad,
+                             guards=(lo["h1_guard"], lo["h2_guard"]) if "h1_guard" in lo else None)
             if self.grad_range_hook is not None:
                 # the sub-band segment (LSTM + head: the tail of the flat buffer) is final once these GEMMs are done
                 self.grad_range_hook(G, self.fp.off["sb_model.sequence_model.weight_ih_l0"][0], G.numel())

@@ -159,9 +159,13 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
     tag = ("lstm", id(packed), train)
     out = {}
     if train:
+        # N zero guard rows in front (h_{-1} = 0): `h1_guard` row r is h1 row r - N, the B operand of the weight-gradient
+        # product that pairs the gate gradients of step t with h_{t-1} without shifting the gate gradients
         Rp = padded_rows(Tn * N, N)
-        out["h1_rows"] = workspace(tag + ("h1",), (Rp, Hd), dt, dev, zero=True)
-        out["h2_rows"] = workspace(tag + ("h2",), (Rp, Hd), dt, dev, zero=True)
+        out["h1_guard"] = workspace(tag + ("h1",), (N + Rp, Hd), dt, dev, zero=True)
+        out["h2_guard"] = workspace(tag + ("h2",), (N + Rp, Hd), dt, dev, zero=True)
+        out["h1_rows"] = out["h1_guard"][N:]
+        out["h2_rows"] = out["h2_guard"][N:]
         out["h1"] = rows_view(out["h1_rows"], Tn, N)
         out["h2"] = rows_view(out["h2_rows"], Tn, N)
         out["c1"] = workspace(tag + ("c1",), (Tn, N, Hd), dt, dev)

@@ -92,6 +92,13 @@ int nppc_gemm_tn_splitk(const void* A, long lda, const void* B, long ldb, float*
  * N % 128 == 0, (R / ksplit) % 64 == 0, at least 256 workgroups; NPPC_EUNSUPPORTED otherwise) */
 int nppc_gemm_tn_splitk_rowsum(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,
                                int ksplit, float* rowsum, void* stream);
+/* two B operands side by side behind ONE pass over A: C_slab[z][m][0 .. N1) = A^T . B1, C_slab[z][m][N1 .. N1 + N2) = A^T . B2
+ * over the rows of K slice z (the weight gradients of one LSTM layer, W_ih | W_hh, share their gate gradients: torch's
+ * autograd of nn.LSTM, audio_zen/model/module/sequence_model.py:113-123, computes them as separate products).  rowsum
+ * optional ([ksplit][M], as above).  bf16; M % 256 == 0, N1 % 192 == 0, N2 == 64 or N2 % 192 == 0, (R / ksplit) % 64 == 0,
+ * ldc >= N1 + N2, at least 256 workgroups; NPPC_EUNSUPPORTED otherwise (run the products separately) */
+int nppc_gemm_tn_splitk2(const void* A, long lda, const void* B1, long ldb1, int N1, const void* B2, long ldb2, int N2, float* C,
+                         long ldc, int M, long R, int ksplit, float* rowsum, void* stream);
 int nppc_gemm_tn_splitk_batched(const void* A, long lda, long sA, const void* B, long ldb, long sB, float* C, long ldc, long sC,
                                 int M, int N, long R, int ksplit, int batch, void* stream);
 int nppc_gemm_tn_splitk_taps(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, long R,

@@ -103,3 +103,35 @@ def test_gemm_tn_rowsum_is_the_column_sum_of_the_a_operand():
     assert float((rs.cpu().double() - want).abs().max()) < 1e-3 * float(want.abs().max())
     with pytest.raises(RuntimeError, match="unsupported"):
         H.call("nppc_gemm_tn_splitk_rowsum", A, M, B, N, C, N, 128, 64, 1024, 2, rs, H.stream())
+
+
+@pytest.mark.parametrize("N2", [64, 384])
+def test_gemm_tn_two_sources_share_one_pass_over_a(N2):
+    """nppc_gemm_tn_splitk2: [A^T . B1 | A^T . B2] in one launch (the two weight gradients of an LSTM layer behind one pass over
+    its gate gradients): 192-column tiles from B1, then 192-column tiles (N2 = 384) or ONE 64-column tile (N2 = 64: the
+    layer-1 input rows) from B2, slab row stride N1 + N2, optional row sums of A; B1 may start before its buffer's live rows
+    (the zero guard rows that stand for h_{-1}): here a shifted view of a larger buffer"""
+    from nppc_audio import _hip as H
+    M, N1, S = 1536, 384, 64
+    R, shift = 64 * S * 2, 96
+    g = torch.Generator().manual_seed(5 + N2)
+    A = (torch.randn(R, M, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    B1buf = torch.randn(R + shift, N1, generator=g).cuda().to(torch.bfloat16)
+    B1buf[:shift] = 0
+    B2 = torch.randn(R, N2, generator=g).cuda().to(torch.bfloat16)
+    ldc = N1 + N2
+    C = torch.full((S, M, ldc), float("nan"), dtype=torch.float32, device="cuda")
+    rs = torch.full((S, M), float("nan"), device="cuda")
+    for B1, rsum in ((B1buf[shift:], rs), (B1buf, None)):           # un-shifted with row sums; guard view without
+        C.fill_(float("nan"))
+        H.call("nppc_gemm_tn_splitk2", A, M, B1, N1, N1, B2, N2, N2, C, ldc, M, R, S, rsum, H.stream())
+        torch.cuda.synchronize()
+        got = C.sum(0).cpu().double()
+        Ad = A.float().cpu().double()
+        ref = torch.cat([Ad.t() @ B1[:R].float().cpu().double(), Ad.t() @ B2.float().cpu().double()], dim=1)
+        assert bool(torch.isfinite(got).all())
+        assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    want = A.float().view(S, R // S, M).double().sum(dim=1).cpu()
+    assert float((rs.cpu().double() - want).abs().max()) < 1e-3 * float(want.abs().max())
+    with pytest.raises(RuntimeError, match="unsupported"):
+        H.call("nppc_gemm_tn_splitk2", A, M, B1buf, N1, 128, B2, N2, N2, C, ldc, M, R, S, None, H.stream())
