@@ -957,19 +957,20 @@ __device__ __forceinline__ int dr_logical(int bytes_in_row, int key, int nch) { 
 // One 256 x BN output tile of one K slice: A rows [rbaseA, rbaseA + Rz) x columns [m0, m0 + 256), B rows [rbaseB, ...) x
 // columns [n0, n0 + BN) -> Cz[m0 + ..][c0 + ..] (c0: the tile's first column in the slab, = n0 unless B is one of several
 // sources side by side); `rs` != nullptr: also the row sums of the A tile -> rs[m0 + ..].
-template <int BN, int BR, int STAGES>
+template <int BM, int BN, int BR, int STAGES>
 __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                          float* __restrict__ Cz, long ldc, long m0, long n0, long c0, long rbaseA, long rbaseB,
                                          long Rz, float* __restrict__ rs) {
   constexpr int KS = BR / 32;                                   // 32-deep MFMA k-steps per stage
-  constexpr int A_BYTES = BR * DR_BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BR * BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int MI = BM / 64;                                   // 16-row tiles per wave (4 waves across M)
   constexpr int NA = A_BYTES / 1024 / 8;                        // whole 1 KB DMA pieces per wave and stage (A)
   constexpr int BW = B_BYTES / 8;                               // B bytes per wave and stage: NBF whole pieces + one half piece
   constexpr int NBF = BW / 1024, NBH = (BW % 1024) / 512;
   static_assert(A_BYTES % 8192 == 0 && BW % 512 == 0 && NBH <= 1, "DMA pieces must divide evenly over the 8 waves");
   constexpr int NDMA = NA + NBF + NBH;                          // DMA instructions per wave and stage (the vmcnt unit)
   constexpr int NJ = BN / 32;                                   // 16-column tiles per wave (2 waves across N)
-  constexpr int ACH = DR_BM * 2 / 32, BCH = BN * 2 / 32;        // 32-byte chunks per row
+  constexpr int ACH = BM * 2 / 32, BCH = BN * 2 / 32;           // 32-byte chunks per row
   extern __shared__ __attribute__((aligned(1024))) unsigned char dr_lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
@@ -983,8 +984,9 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
   const unsigned char* srcB[NBF + NBH];
 #pragma unroll
   for (int h = 0; h < NA; ++h) {
-    const int row = 2 * (NA * wave + h) + (lane >> 5);
-    const int p = dr_logical((lane & 31) * 16, dr_key(row, ACH), ACH);
+    const int o = (NA * wave + h) * 1024 + lane * 16;           // byte offset inside the stage's A image (rows of BM*2 bytes)
+    const int row = o / (BM * 2);
+    const int p = dr_logical(o % (BM * 2), dr_key(row, ACH), ACH);
     srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbaseA + row) * lda + m0) + p;
   }
 #pragma unroll
@@ -1012,7 +1014,7 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
     for (int h = 0; h < NA; ++h) dma(srcA[h] + st * strA, l + (NA * wave + h) * 1024);
 #pragma unroll
     for (int h = 0; h < NBF; ++h) dma(srcB[h] + st * strB, l + A_BYTES + wave * BW + h * 1024);
-    if (NBH) {
+    if constexpr (NBH != 0) {
       if (lane < 32) dma(srcB[NBF] + st * strB, l + A_BYTES + wave * BW + NBF * 1024);
     }
   };
@@ -1030,18 +1032,18 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  f32x4 acc[4][NJ];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // rowsum (optional): sum_r A[r][m] over the K slice -- the A fragments times an all-ones B fragment, by the waves that
   // hold column tile 0 (a few extra MFMAs): a bias gradient comes out of the weight-gradient product that reads the same
   // gate gradients, instead of out of a second pass over them
   const bool do_rowsum = rs != nullptr && wn == 0;
-  f32x4 racc[4];
+  f32x4 racc[MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MI; ++i) racc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((ext_vector_type(8))) short ones_t;
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
@@ -1068,38 +1070,38 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
     const unsigned char* tb = ta + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 af[4], bfr[NJ];
+      bf16x8 af[MI], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = tfrag(ta, DR_BM * 2, ACH, ks, wm * 64 + 16 * i);
+      for (int i = 0; i < MI; ++i) af[i] = tfrag(ta, BM * 2, ACH, ks, wm * (BM / 4) + 16 * i);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bfr[j] = tfrag(tb, BN * 2, BCH, ks, wn * (BN / 2) + 16 * j);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bfr[j], acc[i][j]);
       if (do_rowsum) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) racc[i] = mma16(af[i], ones, racc[i]);
+        for (int i = 0; i < MI; ++i) racc[i] = mma16(af[i], ones, racc[i]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are complete before it can reach the next barrier
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long row = m0 + wm * 64 + 16 * i + 4 * qq + r;
+        const long row = m0 + wm * (BM / 4) + 16 * i + 4 * qq + r;
         const long col = c0 + wn * (BN / 2) + 16 * j + i16;
         Cz[row * ldc + col] = acc[i][j][r];
       }
   if (do_rowsum && i16 == 0) {                      // every column of racc holds the row sum: lane column 0 stores it
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rs[m0 + wm * 64 + 16 * i + 4 * qq + r] = racc[i][r];
+      for (int r = 0; r < 4; ++r) rs[m0 + wm * (BM / 4) + 16 * i + 4 * qq + r] = racc[i][r];
   }
 }
 
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
   const long boff = ntap == 9 ? (long)(tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
   const long rbase = (long)(bz % ksl) * Rz;
   float* rs = rowsum != nullptr && by == 0 ? rowsum + ((size_t)bb * nzb + bz) * ((size_t)gridDim.x * DR_BM) : nullptr;
-  dma_tile<BN, BR, STAGES>(A, lda, B, ldb, C + (size_t)bz * slab_stride, ldc, (long)bx * DR_BM, (long)by * BN, (long)by * BN,
+  dma_tile<DR_BM, BN, BR, STAGES>(A, lda, B, ldb, C + (size_t)bz * slab_stride, ldc, (long)bx * DR_BM, (long)by * BN, (long)by * BN,
                            rbase + (shift_a ? boff : 0), rbase + (shift_a ? 0 : boff), Rz, rs);
 }
 
@@ -1143,23 +1145,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(const bf16_t* __res
 // B2.  All column tiles of a K slice run on one XCD at about the same time, so the A rows come from HBM once and from that
 // XCD's L2 for the other tiles: the LSTM weight gradients that share their gate gradients (W_ih | W_hh of a layer) cost one
 // pass over them instead of two or three.
-template <int BR, int STAGES>
+template <int BM, int BR, int STAGES>
 __global__ __launch_bounds__(512, 1) void gemm_tn_dma2_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B1,
                                                               long ldb1, int nt1, const bf16_t* __restrict__ B2, long ldb2, int N2,
                                                               float* __restrict__ C, long ldc, long slab_stride, long Rz,
                                                               float* __restrict__ rowsum) {
   unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   dr_xcd_remap(bx, by, bz);
-  const long m0 = (long)bx * DR_BM, rbase = (long)bz * Rz;
+  const long m0 = (long)bx * BM, rbase = (long)bz * Rz;
   float* Cz = C + (size_t)bz * slab_stride;
-  float* rs = rowsum != nullptr && by == 0 ? rowsum + (size_t)bz * ((size_t)gridDim.x * DR_BM) : nullptr;
+  float* rs = rowsum != nullptr && by == 0 ? rowsum + (size_t)bz * ((size_t)gridDim.x * BM) : nullptr;
   if ((int)by >= nt1 && N2 == 64) {
-    dma_tile<64, BR, STAGES>(A, lda, B2, ldb2, Cz, ldc, m0, 0, (long)nt1 * 192, rbase, rbase, Rz, nullptr);
+    dma_tile<BM, 64, BR, STAGES>(A, lda, B2, ldb2, Cz, ldc, m0, 0, (long)nt1 * 192, rbase, rbase, Rz, nullptr);
     return;
   }
   const bool second = (int)by >= nt1;
   const long n0 = (long)(second ? by - nt1 : by) * 192;
-  dma_tile<192, BR, STAGES>(A, lda, second ? B2 : B1, second ? ldb2 : ldb1, Cz, ldc, m0, n0, (long)by * 192, rbase, rbase, Rz, rs);
+  dma_tile<BM, 192, BR, STAGES>(A, lda, second ? B2 : B1, second ? ldb2 : ldb1, Cz, ldc, m0, n0, (long)by * 192, rbase, rbase, Rz, rs);
 }
 
 }  // namespace
@@ -1276,20 +1278,38 @@ extern "C" int nppc_gemm_tn_splitk2(const void* A, long lda, const void* B1, lon
                                     float* C, long ldc, int M, long R, int ksplit, float* rowsum, void* stream) {
   if (!A || !B1 || !B2 || !C || M <= 0 || N1 <= 0 || N2 <= 0 || R <= 0 || ksplit < 1) return NPPC_EBADARG;
   if (lda % 8 || ldb1 % 8 || ldb2 % 8 || ldc < N1 + N2) return NPPC_EBADARG;
-  if (!tn_dma() || M % DR_BM || N1 % 192 || (N2 != 64 && N2 % 192) || R % ksplit || (R / ksplit) % 64) return NPPC_EUNSUPPORTED;
+  if (!tn_dma() || N1 % 192 || (N2 != 64 && N2 % 192) || R % ksplit || (R / ksplit) % 64) return NPPC_EUNSUPPORTED;
   const int nt1 = N1 / 192, nt2 = N2 == 64 ? 1 : N2 / 192;
-  if ((long)(M / DR_BM) * (nt1 + nt2) * ksplit < 256) return NPPC_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  // 384-row tiles (4 stages of 32 K-rows) when M allows: 128 FLOP per operand byte in flight instead of 110, and for the
+  // LSTM shapes (M = 1536, 64 K slices) 4 x 4 x 64 = 1024 and 4 x 3 x 64 = 768 workgroups = whole rounds of the 256 CUs;
+  // NPPC_TN_BM384=0 keeps the 256-row tiles (A/B switch)
+  static const bool bm384 = [] { const char* e = getenv("NPPC_TN_BM384"); return !(e && e[0] == '0'); }();
+  if (bm384 && M % 384 == 0 && (long)(M / 384) * (nt1 + nt2) * ksplit >= 256) {
+    constexpr int smem = 4 * (32 * 384 * 2 + 32 * 192 * 2);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma2_kernel<384, 32, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        return NPPC_ELAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_dma2_kernel<384, 32, 4>), dim3(M / 384, nt1 + nt2, ksplit), dim3(512), smem, s, (const bf16_t*)A, lda,
+                       (const bf16_t*)B1, ldb1, nt1, (const bf16_t*)B2, ldb2, N2, C, ldc, (long)M * ldc, R / ksplit, rowsum);
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
+  if (M % DR_BM || (long)(M / DR_BM) * (nt1 + nt2) * ksplit < 256) return NPPC_EUNSUPPORTED;
   constexpr int smem = 5 * (32 * DR_BM * 2 + 32 * 192 * 2);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma2_kernel<32, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_dma2_kernel<DR_BM, 32, 5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return NPPC_ELAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_tn_dma2_kernel<32, 5>), dim3(M / DR_BM, nt1 + nt2, ksplit), dim3(512), smem, (hipStream_t)stream,
-                     (const bf16_t*)A, lda, (const bf16_t*)B1, ldb1, nt1, (const bf16_t*)B2, ldb2, N2, C, ldc, (long)M * ldc,
-                     R / ksplit, rowsum);
+  hipLaunchKernelGGL((gemm_tn_dma2_kernel<DR_BM, 32, 5>), dim3(M / DR_BM, nt1 + nt2, ksplit), dim3(512), smem, s, (const bf16_t*)A,
+                     lda, (const bf16_t*)B1, ldb1, nt1, (const bf16_t*)B2, ldb2, N2, C, ldc, (long)M * ldc, R / ksplit, rowsum);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -105,14 +105,15 @@ def test_gemm_tn_rowsum_is_the_column_sum_of_the_a_operand():
         H.call("nppc_gemm_tn_splitk_rowsum", A, M, B, N, C, N, 128, 64, 1024, 2, rs, H.stream())
 
 
+@pytest.mark.parametrize("M", [1536, 1280])       # 384-row tiles (M % 384 == 0) and the 256-row fallback geometry
 @pytest.mark.parametrize("N2", [64, 384])
-def test_gemm_tn_two_sources_share_one_pass_over_a(N2):
+def test_gemm_tn_two_sources_share_one_pass_over_a(N2, M):
     """nppc_gemm_tn_splitk2: [A^T . B1 | A^T . B2] in one launch (the two weight gradients of an LSTM layer behind one pass over
     its gate gradients): 192-column tiles from B1, then 192-column tiles (N2 = 384) or ONE 64-column tile (N2 = 64: the
     layer-1 input rows) from B2, slab row stride N1 + N2, optional row sums of A; B1 may start before its buffer's live rows
     (the zero guard rows that stand for h_{-1}): here a shifted view of a larger buffer"""
     from nppc_audio import _hip as H
-    M, N1, S = 1536, 384, 64
+    N1, S = 384, 64
     R, shift = 64 * S * 2, 96
     g = torch.Generator().manual_seed(5 + N2)
     A = (torch.randn(R, M, generator=g) * 0.5).cuda().to(torch.bfloat16)
