@@ -376,16 +376,21 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       }
     }
     const bool more = t + 1 < a.Tn;
-    if (more) {
-      // x_{t+1} -> the X buffer this step does not read, by LDS-DMA as well (one 128-byte row per instruction,
-      // non-temporal: read once)
-      typedef __attribute__((address_space(3))) void lds_void;
+    // x_{t+1} -> the X buffer this step does not read, by LDS-DMA as well (one 128-byte row per instruction,
+    // non-temporal: read once).  Issued BEHIND layer 1's GEMMs, in front of its pointwise phase and the two barriers: a
+    // wave's vector-memory operations retire in order, so at the top of the step this HBM read sat in front of the first
+    // weight fragments of layer 1 and every wave waited out its latency there (0.3 ms per launch; here the pointwise
+    // phase covers most of it: restorer forward 9.10 -> 8.93 ms, tools/diag/lstm_variants.py)
+    auto x_prefetch = [&]() {
+      if (more) {
+        typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll 1
-      for (int r = wave; r < MC; r += NW)
-        if (row0 + r < N && lane < cpr)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(lds + r * RS + (p ? OX0 : OX1)), 16, lane * 16,
-                                                   (int)((((size_t)(t + 1) * N + row0 + r) * KX) * sizeof(T)), 0, 2);
-    }
+        for (int r = wave; r < MC; r += NW)
+          if (row0 + r < N && lane < cpr)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(lds + r * RS + (p ? OX0 : OX1)), 16, lane * 16,
+                                                     (int)((((size_t)(t + 1) * N + row0 + r) * KX) * sizeof(T)), 0, 2);
+      }
+    };
     constexpr bool PR = MT <= 2;                                   // prime the next weight segment across sync points
     typename Frag<T>::type pre[DEPTH - 1][2];
     // ================= layer 1: [x_t | h1_{t-1}] =================
@@ -416,9 +421,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + (p ? OX1 : OX0), 0, NKX, 0, nk1, wr1, 1, ublk, lane);
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, NKX, nk1, wr1, 1, ublk, lane);
       // every vector-memory operation issued so far has completed here anyway (the ring just consumed its last, youngest
-      // fragment and vmcnt retires in order): make the completion of this step's LDS-DMA transfers (partner h2, next x)
-      // explicit before the barriers that publish them to the other waves
+      // fragment and vmcnt retires in order): make the completion of this step's LDS-DMA transfer (partner h2) explicit
+      // before the barriers that publish it to the other waves; the next x follows and is drained by barrier (1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      x_prefetch();
       FT(1)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -445,7 +451,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) hw_lane[OH1 + (16 * mt + j) * RS] = from_f32<T>(hn1[mt][j]);
-    __syncthreads();                                              // (2a) own h1_t slice complete in LDS (drains the x DMA too)
+    __syncthreads();                                              // (2a) own h1_t slice complete in LDS
     FT(3)
     publish(0, OH1, ep);
     FT(4)
