@@ -554,12 +554,32 @@ class FSNEngine:
         tA = ws("tA", (3, max(Cr, TCN_HIDDEN, Fr), R), zero=True)       # transposed dY operand
         tB = ws("tB", (3, max(ldC, TCN_HIDDEN), R), zero=True)          # transposed activation operand
         slab2 = ws("slab2", (3 * S2 * max(Cr * TCN_HIDDEN, TCN_HIDDEN * ldC, Fr * ldC),), torch.float32)
-        H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, s)
         X8 = d["X"][8]
         sTA, sTB = tA.shape[1] * R, tB.shape[1] * R
-        H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, s)
-        H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, s)
-        self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
+
+        def on_side(fn):
+            """run fn (which launches on the current stream) on the side stream once the main stream got here"""
+            if not TCN_WGRAD_ON_SIDE:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                fn()
+
+        def fc_wgrad():
+            # parameter gradients only (bias: column sums; weight: two transposes + the NT split-K product -- F and C are not
+            # multiples of the TN kernel's tiles): off the main chain, which goes straight on to the input gradient
+            q = H.stream()
+            H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, q)
+            H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, q)
+            H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, q)
+            self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
+        # (the generic path below re-uses tA / tB / slab2 on the main stream: there the product stays in line)
+        if prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0:
+            on_side(fc_wgrad)
+        else:
+            fc_wgrad()
         # bf16: the 1x1-conv weight gradients run on the TN GEMM straight from the row-major activations (no transposes)
         tn_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
         if tn_ok:
@@ -573,16 +593,6 @@ class FSNEngine:
         else:
             dXa = ws("dXa", (3, B, Tp, ldC))
             dXb = ws("dXb", (3, B, Tp, ldC))
-
-        def on_side(fn):
-            """run fn (which launches on the current stream) on the side stream once the main stream got here"""
-            if not TCN_WGRAD_ON_SIDE:
-                return fn()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                fn()
 
         H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
                X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
