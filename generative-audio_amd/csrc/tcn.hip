@@ -33,6 +33,9 @@ struct GemmArgs {
   int ksplit;                              // >1: blockIdx.z = batch*ksplit + s; slice s covers K elements [s*K, (s+1)*K)
   const float* gnv; long strideGnv;        // EPI_RESIDUAL_GN: v[N]; `stats` then holds the GroupNorm (sum, sumsq) per sample
   double gcnt; float geps;                 // ... elements per sample, epsilon
+  float* colpart; long strideColpart;      // optional (LDS kernels, EPI_RESIDUAL / EPI_MASK_POS): column sums of each 128-row tile of
+                                           // the OUTPUT, [z][R/128][N] fp32 -- the bias gradient of the layer that consumes C as its
+                                           // upstream gradient, without a pass of its own over C
 };
 
 template <typename T> __device__ __forceinline__ typename Frag<T>::type relu_frag(typename Frag<T>::type f);
@@ -277,8 +280,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
     gnv = g.gnv + (size_t)z * g.strideGnv;
   }
   float s1 = 0.f, s2 = 0.f;
+  float cs[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
+    cs[j] = 0.f;
     const int col = n0 + wn * (BN / 2) + 16 * j + n;
     const bool cvalid = col < g.Nv;
     float bv = (bias && cvalid) ? bias[col] : 0.f;
@@ -307,12 +312,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
         }
         const T o = from_f32<T>(v);
         C[(size_t)row * g.ldc + col] = o;
+        if (EPI == EPI_RESIDUAL || EPI == EPI_MASK_POS) cs[j] += to_f32<T>(o);
         if (EPI == EPI_PRELU_STATS) {
           const float vo = to_f32<T>(o);
           s1 += vo;
           s2 += vo * vo;
         }
       }
+  }
+  if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_MASK_POS) {
+    if (g.colpart) {                         // column sums of this 128-row output tile (as stored): 16 rows per lane -> 64 per
+      __shared__ float cpl[2][BN];           // wave (lanes n, n+16, n+32, n+48) -> the two waves along M -> one store per column
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float c = cs[j];
+        c += __shfl_xor(c, 16);
+        c += __shfl_xor(c, 32);
+        if (q == 0) cpl[wm][wn * (BN / 2) + 16 * j + n] = c;
+      }
+      __syncthreads();
+      if (tid < BN)
+        g.colpart[(size_t)z * g.strideColpart + (size_t)blockIdx.x * g.N + n0 + tid] = cpl[0][tid] + cpl[1][tid];
+    }
   }
   if (EPI == EPI_PRELU_STATS) {
     // one sample per 128-row tile (Tp % 128 == 0): one atomic pair per workgroup
@@ -485,12 +506,10 @@ __global__ __launch_bounds__(64) void pack_sconv_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" {
-
-int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
-                 long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
-                 long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
-                 int batch, int ksplit, void* stream) {
+static int launch_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                     long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
+                     long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
+                     int batch, int ksplit, float* colpart, void* stream) {
   if (!A || !B || !C || R <= 0 || N <= 0 || K <= 0 || batch <= 0) return NPPC_EBADARG;
   if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   if (epi == EPI_PRELU_STATS && (!slope || !stats)) return NPPC_EBADARG;
@@ -499,10 +518,12 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
   if (ksplit < 1) ksplit = 1;
   if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
-             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f};
+             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f, colpart, (long)(R / 128) * N};
   hipStream_t s = (hipStream_t)stream;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   const int lds_path = ((K / ksplit) % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
+  // the tile column sums come out of the LDS kernels' epilogue for the two epilogues that produce an upstream gradient
+  if (colpart && (lds_path == 0 || ksplit != 1 || (epi != EPI_RESIDUAL && epi != EPI_MASK_POS))) return NPPC_EUNSUPPORTED;
   dim3 grid(R / 128, lds_path == 128 ? N / 128 : N / 64, batch * ksplit);
 #define LAUNCH(TT, E)                                                                              \
   do {                                                                                             \
@@ -536,6 +557,28 @@ int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void
 #undef LAUNCH
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
+}
+
+extern "C" {
+
+int nppc_gemm_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                 long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
+                 long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
+                 int batch, int ksplit, void* stream) {
+  return launch_nt(prec, epi, A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats, R, N,
+                   K, Tp, Tv, Nv, relu_in, batch, ksplit, nullptr, stream);
+}
+
+// nppc_gemm_nt (EPI_RESIDUAL or EPI_MASK_POS, LDS-staged shapes: K a multiple of 64 (bf16) / 32 (fp32), no K split) that also
+// leaves colpart[z][R/128][N] = the column sums of every 128-row tile of the stored output: C is the upstream gradient of a
+// 1x1 convolution further down the backward chain, whose bias gradient is the sum of these partials over the tiles
+// (nppc_tcn_mid_bwd adds them up) -- no pass of its own over C.
+int nppc_gemm_nt_colsum(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                        long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, int R, int N, int K,
+                        int Tp, int Tv, int Nv, int batch, float* colpart, void* stream) {
+  if (!colpart) return NPPC_EBADARG;
+  return launch_nt(prec, epi, A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, nullptr, 0, nullptr, 0, R, N, K,
+                   Tp, Tv, Nv, 0, batch, 1, colpart, stream);
 }
 
 // sconv with the GroupNorm in front of it folded in (EPI_RESIDUAL_GN above):

@@ -305,6 +305,9 @@ struct MidBwdArgs {
   int Cc, Tp, Tv, dil; float eps;
   long sAct, sSt, sP;
   float* part;
+  // optional: tile column sums of the block's upstream gradient (nppc_gemm_nt_colsum: [z][cp_tiles][cp_ld]) -> the sconv bias
+  // gradient dbias2[z*sP + c], c < cp_cols, added up by the finishing launch
+  const float* colpart; int cp_tiles, cp_ld, cp_cols; float* dbias2;
 };
 __host__ __device__ __forceinline__ size_t mb_part_stride(int Cc) { return (size_t)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG) + 6; }
 
@@ -501,10 +504,25 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
 
 // sums the per-workgroup partials over the samples and ADDS them to the parameter gradients of branch blockIdx.y.
 // One workgroup = 64 consecutive partial columns x 16 slices of the sample list (256 contiguous bytes per load instruction).
-__global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int B) {
+__global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int B, int nb_main) {
   __shared__ float red[16][64];
   const int z = blockIdx.y, Cc = g.Cc;
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= nb_main) {                   // workgroups behind the main ones: the sconv bias gradient from tile sums
+    const int c = ((int)blockIdx.x - nb_main) * 64 + col;
+    float s = 0.f;
+    if (c < g.cp_cols) {
+      const float* p = g.colpart + (size_t)z * g.cp_tiles * g.cp_ld + c;
+      for (int t = slice; t < g.cp_tiles; t += 16) s += p[(size_t)t * g.cp_ld];
+    }
+    red[slice][col] = s;
+    __syncthreads();
+    if (slice != 0 || c >= g.cp_cols) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][col];
+    g.dbias2[(size_t)z * g.sP + c] = s;
+    return;
+  }
   const int i = blockIdx.x * 64 + col;
   const int ncg = Cc / MB_CG, ncols = MB_PART_ROWS * Cc + 2 * ncg;
   const size_t ps = mb_part_stride(Cc);
@@ -597,16 +615,19 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
                      float* part,
                      const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, const float* wd,
                      const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
-                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1, int B,
+                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1,
+                     const float* colpart, int cp_tiles, int cp_ld, int cp_cols, float* dbias2, int B,
                      int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
   if (!dA || !y2 || !y1 || !st1 || !st2 || !S || !part || !gamma1 || !beta1 || !gamma2 || !beta2 || !wd || !slope1 || !slope2 || !dpre1 ||
       !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || dil < 1)
     return NPPC_EBADARG;
+  if (colpart && (!dbias2 || cp_tiles < 1 || cp_cols < 1 || cp_ld < cp_cols)) return NPPC_EBADARG;
   if (Cc % MB_CG) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(S, 0, sizeof(double) * MB_SUMS * B * batch, s) != hipSuccess) return NPPC_ELAUNCH;   // [batch][B][8], sSt = 2B
   MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
-               dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part};
+               dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part,
+               colpart, cp_tiles, cp_ld, cp_cols, dbias2};
   dim3 grid(Cc / MB_CG, B, batch);
   if (prec == NPPC_PREC_BF16) {
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, g);
@@ -615,7 +636,9 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, g);
     hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), 0, s, g);
   }
-  hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(ceil_div((long)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG), 64), batch), dim3(1024), 0, s, g, B);
+  const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG), 64);
+  hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(nb_main + (colpart ? (int)ceil_div(cp_cols, 64) : 0), batch), dim3(1024), 0, s, g,
+                     B, nb_main);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -112,7 +112,9 @@ SIGS = {
     "nppc_scale_transpose": [I, P, P, P, I, I, I, I, I, I, P],
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_tcn_mid_bwd_part_elems": [I, I, I, I, PL],
-    "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P,
+                         I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_gemm_nt_colsum": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, I, I, I, I, I, I, I, P, P],
     "nppc_gemm_nt_gn": [I, P, L, L, P, L, L, P, L, L, P, P, L, P, L, L, P, L, D, F, I, I, I, I, I, I, I, P],
     "nppc_tcn_pack_sconv": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, P],
     "nppc_gemm_nt_splitk": [I, P, L, P, L, P, L, I, I, L, I, P],

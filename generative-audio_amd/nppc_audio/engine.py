@@ -27,6 +27,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
+COLSUM_IN_GEMM = os.environ.get("NPPC_COLSUM_IN_GEMM", "1") != "0"   # sconv bias gradients from the producing GEMM's epilogue (A/B switch)
 TN_PAIRED = os.environ.get("NPPC_TN_PAIRED", "1") != "0"              # one pass over the gate gradients per LSTM layer (A/B switch)
 FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "3"))    # 0: head kernels; 1: fused in the inference forward; 2: + training forward; 3: + backward
 
@@ -594,8 +595,17 @@ class FSNEngine:
             dXa = ws("dXa", (3, B, Tp, ldC))
             dXb = ws("dXb", (3, B, Tp, ldC))
 
-        H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
-               X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
+        # the GEMMs that PRODUCE a block's upstream gradient also leave its column sums per 128-row tile (epilogue): the sconv
+        # bias gradient is their sum over the tiles, added up by the block's fused middle backward -- no pass over dXo for it
+        bk = 64 if prec == H.PREC_BF16 else 32
+        cs_ok = tn_ok and COLSUM_IN_GEMM and ldF % bk == 0 and TCN_HIDDEN % bk == 0
+        cpL = [ws(f"colpart_{i}", (3, R // 128, ldC), torch.float32) for i in range(8)] if cs_ok else None
+        if cs_ok:
+            H.call("nppc_gemm_nt_colsum", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC,
+                   None, 0, X8, ldC, R * ldC, R, ldC, ldF, Tp, Tv, C, 3, cpL[7], s)
+        else:
+            H.call("nppc_gemm_nt", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC, None, 0,
+                   X8, ldC, R * ldC, None, 0, None, 0, R, ldC, ldF, Tp, Tv, C, 0, 3, 1, s)
         # ---- 6. TCN blocks in reverse
         sAct = B * Tp * TCN_HIDDEN
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
@@ -612,7 +622,8 @@ class FSNEngine:
                 dXo, dXi, a2, h2b = dXL[i + 1], dXL[i], a2L[i], h2L[i]
             else:
                 a2 = d["a2"]
-            H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
+            if not cs_ok:
+                H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
             # dA2 = dXo W2  (gradient of the normalised depthwise output)
             H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
                    sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
@@ -624,8 +635,9 @@ class FSNEngine:
                    self.p(pre + "prelu1.weight"), self.p(pre + "prelu2.weight"), a2, h2b, self.g(pre + "norm2.weight"),
                    self.g(pre + "norm2.bias"), self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"),
                    self.g(pre + "depthwise_conv.weight"), self.g(pre + "depthwise_conv.bias"), self.g(pre + "prelu1.weight"),
-                   self.g(pre + "prelu2.weight"), self.g(pre + "conv1x1.bias"), B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP,
-                   3, s)
+                   self.g(pre + "prelu2.weight"), self.g(pre + "conv1x1.bias"),
+                   cpL[i] if cs_ok else None, R // 128, ldC, C, self.g(pre + "sconv.bias") if cs_ok else None,
+                   B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
             # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
             if tn_ok:
                 # row-major operands as they are: slab[k][c] = sum_r a2[r][k] * dXo[r][c] = dW2^T, transposed in the reduction
@@ -656,8 +668,12 @@ class FSNEngine:
                 H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
                 self._wgrad(tA, R, sTA, tB, R, sTB, TCN_HIDDEN, ldC, R, S2, pre + "conv1x1.weight", C, TCN_HIDDEN, C, slab2,
                             batch=3, sDst=sP)
-            H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
-                   R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
+            if cs_ok and i > 0:
+                H.call("nppc_gemm_nt_colsum", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN,
+                       dXi, ldC, R * ldC, None, 0, dXo, ldC, R * ldC, R, ldC, TCN_HIDDEN, Tp, Tv, C, 3, cpL[i - 1], s)
+            else:
+                H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
+                       R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
             dXo, dXi = dXi, dXo
             if i == 4 and self.grad_range_hook is not None:
                 # TCN blocks 7..4 of every branch are final once both queues have passed this point

@@ -126,13 +126,16 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
  * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][8] fp64 workspace (zeroed by the launcher); part:
  * nppc_tcn_mid_bwd_part_elems(B, Cc, Tp, batch, &n) -> n floats of workspace for per-workgroup partial sums (a third, tiny launch adds
  * them to the gradients: no contended global atomics); a2 (nullable) receives GN2(y2), the operand of the sconv weight
- * gradient.  Gradients are ACCUMULATED into their destinations. */
+ * gradient.  Gradients are ACCUMULATED into their destinations.  colpart (nullable): the tile column sums that
+ * nppc_gemm_nt_colsum left for the block's upstream gradient, [batch][cp_tiles][cp_ld] -> the finishing launch also writes the
+ * sconv bias gradient dbias2[z*sP + c] = sum over the tiles, c < cp_cols (sconv.bias: causal_conv.py:107). */
 int nppc_tcn_mid_bwd_part_elems(int B, int Cc, int Tp, int batch, long* n);
 int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, const double* st1, const double* st2, double* S,
                      float* part,
                      const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, const float* wd,
                      const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
-                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1, int B,
+                     float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1,
+                     const float* colpart, int cp_tiles, int cp_ld, int cp_cols, float* dbias2, int B,
                      int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream);
 /* sconv of a TCNBlock with the GroupNorm in front of it (norm2, causal_conv.py:104-106) folded into the product:
  *   C = rstd_b * (A Wg^T) - mean_b * rstd_b * v + u + res,  A = the un-normalised depthwise output, stats = its per-sample
@@ -141,6 +144,13 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
 int nppc_gemm_nt_gn(int prec, const void* A, long lda, long sA, const void* Wg, long ldb, long sB, void* C, long ldc, long sC,
                     const float* u, const float* v, long sUV, const void* res, long ldres, long sRes, const double* stats,
                     long sStats, double cnt, float eps, int R, int N, int K, int Tp, int Tv, int Nv, int batch, void* stream);
+/* nppc_gemm_nt with epi EPI_RESIDUAL or EPI_MASK_POS (LDS-staged shapes only: K % 64 == 0 in bf16 / % 32 in fp32) that also
+ * leaves colpart[z][R/128][N] (fp32) = the column sums of every 128-row tile of the stored output.  The output is the upstream
+ * gradient of the next 1x1 convolution down the backward chain (causal_conv.py:107, fullsubnet_plus.py fc_output_layer), whose
+ * bias gradient is the sum of these partials over the tiles (nppc_tcn_mid_bwd adds them up): no pass of its own over C. */
+int nppc_gemm_nt_colsum(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
+                        long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, int R, int N, int K,
+                        int Tp, int Tv, int Nv, int batch, float* colpart, void* stream);
 int nppc_tcn_pack_sconv(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* u,
                         float* v, int N, int K, int Npad, int ldd, int n_a, int n_b, long src_stride_a, long src_stride_b,
                         long dst_stride_a, long dst_stride_b, void* stream);

@@ -74,11 +74,20 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     grads = {k: torch.zeros(Z * sP, device="cuda") for k in ("g2", "b2", "g1", "b1", "wd", "bd", "a1", "a2", "bias1")}
     a2_out = torch.zeros(Z, B, Tp, C, dtype=dt, device="cuda")
     dpre1 = torch.full((Z, B, Tp, C), float("nan"), dtype=dt, device="cuda")
+    # optional rider: tile column sums of the block's upstream gradient (what nppc_gemm_nt_colsum leaves) -> sconv bias gradient
+    n_tiles, cp_ld, cp_cols = 5, 320, 257
+    colpart = torch.randn(Z, n_tiles, cp_ld, generator=g).cuda()
+    dbias2 = torch.full((Z * sP,), float("nan"), device="cuda")
     H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], a2_out, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
-           grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
+           grads["a1"], grads["a2"], grads["bias1"], colpart, n_tiles, cp_ld, cp_cols, dbias2, B, C, Tp, Tv, dil, EPS, B * Tp * C,
+           B * 2, sP, Z, H.stream())
     torch.cuda.synchronize()
     tol = 2e-4 if prec == 1 else 4e-2
+    for z in range(Z):
+        want_b2 = colpart[z, :, :cp_cols].double().sum(0).cpu()
+        assert float((dbias2[z * sP: z * sP + cp_cols].double().cpu() - want_b2).abs().max()) < 1e-5 * float(want_b2.abs().max())
+        assert bool(torch.isnan(dbias2[z * sP + cp_cols: (z + 1) * sP]).all())              # nothing written past the valid columns
 
     def rel(got, ref):
         return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
@@ -97,7 +106,8 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     # accumulate semantics: a second launch doubles the parameter gradients
     H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], None, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
-           grads["a1"], grads["a2"], grads["bias1"], B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, H.stream())
+           grads["a1"], grads["a2"], grads["bias1"], None, 0, 0, 0, None, B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z,
+           H.stream())
     torch.cuda.synchronize()
     got2 = torch.stack([grads["g1"][z * sP: z * sP + C] for z in range(Z)])
     assert rel(got2, 2 * Pr["g1"].grad) < tol
@@ -220,3 +230,35 @@ def test_batched_attention_front_equals_per_map_launches(nm, prec):
     assert float(Gr.abs().max()) > 0
     # fp32 atomics in a different order: equal to summation noise
     assert float((G - Gr).abs().max()) < 1e-5 * float(Gr.abs().max())
+
+
+@pytest.mark.parametrize("prec,epi,N,K", [(0, 2, 576, 512), (0, 5, 576, 320), (1, 2, 128, 96), (0, 2, 512, 128)])
+def test_gemm_epilogue_leaves_tile_column_sums_of_the_output(prec, epi, N, K):
+    """nppc_gemm_nt_colsum: the same output as nppc_gemm_nt (EPI_RESIDUAL = 2 / EPI_MASK_POS = 5) plus the column sums of every
+    128-row tile of the STORED output -- the bias gradient of the next 1x1 convolution down the backward chain
+    (causal_conv.py:107) without a pass of its own over that tensor"""
+    from nppc_audio import _hip as H
+    Z, B, Tp, Tv, Nv = 3, 2, 256, 200, N - 7
+    R = B * Tp
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(N + K + epi)
+    A = torch.randn(Z, R, K, generator=g).to(dt).cuda()
+    W = (torch.randn(Z, N, K, generator=g) * 0.1).to(dt).cuda()
+    res = torch.randn(Z, R, N, generator=g).to(dt).cuda()
+    out0 = torch.full((Z, R, N), float("nan"), dtype=dt, device="cuda")
+    out1 = torch.full((Z, R, N), float("nan"), dtype=dt, device="cuda")
+    cp = torch.full((Z, R // 128, N), float("nan"), device="cuda")
+    H.call("nppc_gemm_nt", prec, epi, A, K, R * K, W, K, N * K, out0, N, R * N, None, 0, res, N, R * N, None, 0, None, 0, R, N, K,
+           Tp, Tv, Nv, 0, Z, 1, H.stream())
+    H.call("nppc_gemm_nt_colsum", prec, epi, A, K, R * K, W, K, N * K, out1, N, R * N, None, 0, res, N, R * N, R, N, K, Tp, Tv, Nv,
+           Z, cp, H.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1)
+    want = out1.double().view(Z, R // 128, 128, N).sum(2).cpu()
+    assert bool(torch.isfinite(cp).all())
+    assert float((cp.double().cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    if prec == 1:
+        return
+    with pytest.raises(RuntimeError, match="unsupported"):               # K not a multiple of the bf16 LDS stage: no silent fallback
+        H.call("nppc_gemm_nt_colsum", prec, epi, A, K, R * K, W, K, N * K, out1, N, R * N, None, 0, res, N, R * N, R, N, 32, Tp, Tv,
+               Nv, Z, cp, H.stream())
