@@ -33,6 +33,7 @@ struct GemmArgs {
   int ksplit;                              // >1: blockIdx.z = batch*ksplit + s; slice s covers K elements [s*K, (s+1)*K)
   const float* gnv; long strideGnv;        // EPI_RESIDUAL_GN: v[N]; `stats` then holds the GroupNorm (sum, sumsq) per sample
   double gcnt; float geps;                 // ... elements per sample, epsilon
+  int staged;                              // LDS kernels, residual / mask epilogues: coalesced epilogue through LDS (ldc, ldres % 8 == 0)
   float* colpart; long strideColpart;      // optional (LDS kernels, EPI_RESIDUAL / EPI_MASK_POS): column sums of each 128-row tile of
                                            // the OUTPUT, [z][R/128][N] fp32 -- the bias gradient of the layer that consumes C as its
                                            // upstream gradient, without a pass of its own over C
@@ -279,6 +280,78 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
     gn_mr = (float)m * gn_rstd;
     gnv = g.gnv + (size_t)z * g.strideGnv;
   }
+  if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_GN || EPI == EPI_MASK_POS) {
+    if (g.staged) {
+      // Coalesced epilogue.  In the accumulator layout a lane owns 2-byte elements of 32 different (row, column) pairs: the
+      // residual came in as 32 dependent 2-byte gathers per lane AFTER the K loop (19 of the sconv product's 59 us) and the
+      // output left the same way.  Here the tile goes through the LDS operand buffers (free after the loop) as fp32, row stride
+      // BN + 4 words (the four row groups of a wave land on four different bank quarters), and comes back as 16-byte chunks of
+      // a row: ONE 16-byte residual load and ONE 16-byte store per 8 outputs.
+      constexpr int LD = BN + 4, VE = 8, CPR = BN / VE;
+      constexpr int HALVES = (128 * LD * 4 <= (int)sizeof(lds)) ? 1 : 2;   // BN = 128: two passes of 64 rows
+      constexpr int ROWS = 128 / HALVES;
+      float* ot = reinterpret_cast<float*>(&lds[0][0]);
+      const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+      float csum[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) csum[e] = 0.f;
+      for (int h = 0; h < HALVES; ++h) {
+        if (HALVES == 1 || wm == h) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn * (BN / 2) + 16 * j + n;
+            const bool cvalid = col < g.Nv;
+            float bv = (bias && cvalid) ? bias[col] : 0.f;
+            if (EPI == EPI_RESIDUAL_GN && cvalid) bv -= gn_mr * gnv[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                ot[((HALVES == 1 ? wm * 64 : 0) + 16 * i + 4 * q + r) * LD + wn * (BN / 2) + 16 * j + n] =
+                    (EPI == EPI_RESIDUAL_GN ? gn_rstd * acc[i][j][r] : acc[i][j][r]) + bv;
+          }
+        }
+        __syncthreads();
+        for (int c = tid; c < ROWS * CPR; c += 256) {
+          const int rl = c / CPR, cc = (c % CPR) * VE;
+          const int row = m0 + h * ROWS * (HALVES - 1) + rl, col = n0 + cc;
+          const bool rvalid = (row % g.Tp) < g.Tv;
+          float v[VE], rv[VE];
+          const float4 lo = *reinterpret_cast<const float4*>(ot + rl * LD + cc), hi = *reinterpret_cast<const float4*>(ot + rl * LD + cc + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+          load8<T>(res + (size_t)row * g.ldres + col, rv);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            float x = v[e];
+            if (EPI == EPI_MASK_POS) { if (!(rv[e] > 0.f)) x = 0.f; }
+            else x += rv[e];
+            if (!(rvalid && col + e < g.Nv)) x = 0.f;
+            v[e] = x;
+            csum[e] += to_f32<T>(from_f32<T>(x));
+          }
+          store8<T>(reinterpret_cast<T*>(g.C) + (size_t)blockIdx.z * g.strideC + (size_t)row * g.ldc + col, v);
+        }
+        if (HALVES == 2) __syncthreads();
+      }
+      if (EPI != EPI_RESIDUAL_GN && g.colpart) {
+        // column sums of the stored tile: a thread's chunk column is the same in every pass (256 % CPR == 0); lanes with the
+        // same chunk are CPR apart in a wave, the four waves meet in LDS
+        __shared__ float cpl[4][BN];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          float cv = csum[e];
+#pragma unroll
+          for (int m = CPR; m < 64; m <<= 1) cv += __shfl_xor(cv, m);
+          if (lane < CPR) cpl[wave][lane * VE + e] = cv;
+        }
+        __syncthreads();
+        if (tid < BN)
+          g.colpart[(size_t)z * g.strideColpart + (size_t)blockIdx.x * g.N + n0 + tid] =
+              cpl[0][tid] + cpl[1][tid] + cpl[2][tid] + cpl[3][tid];
+      }
+      return;
+    }
+  }
   float s1 = 0.f, s2 = 0.f;
   float cs[NJ];
 #pragma unroll
@@ -506,6 +579,16 @@ __global__ __launch_bounds__(64) void pack_sconv_kernel(const float* __restrict_
 
 }  // namespace
 
+// NPPC_NT_STAGED=0: residual / mask epilogues in the accumulator layout (A/B switch for the coalesced epilogue)
+static int nt_staged() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NPPC_NT_STAGED");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 static int launch_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
                      long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
                      long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
@@ -518,7 +601,8 @@ static int launch_nt(int prec, int epi, const void* A, long lda, long sA, const 
   if (ksplit < 1) ksplit = 1;
   if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
-             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f, colpart, (long)(R / 128) * N};
+             R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f,
+             (res && ldc % 8 == 0 && ldres % 8 == 0 && nt_staged()) ? 1 : 0, colpart, (long)(R / 128) * N};
   hipStream_t s = (hipStream_t)stream;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   const int lds_path = ((K / ksplit) % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
@@ -589,7 +673,7 @@ int nppc_gemm_nt_gn(int prec, const void* A, long lda, long sA, const void* Wg, 
   if (!A || !Wg || !C || !u || !v || !res || !stats || R <= 0 || N <= 0 || K <= 0 || batch <= 0 || cnt <= 0) return NPPC_EBADARG;
   if (R % 128 || N % 64 || K % 32 || Tp <= 0 || (Tp % 128) || lda % 8 || ldb % 8) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, Wg, ldb, sB, C, ldc, sC, u, sUV, res, ldres, sRes, nullptr, 0, const_cast<double*>(stats), sStats,
-             R, N, K, Tp, Tv, Nv, 0, 1, v, sUV, cnt, eps};
+             R, N, K, Tp, Tv, Nv, 0, 1, v, sUV, cnt, eps, (ldc % 8 == 0 && ldres % 8 == 0 && nt_staged()) ? 1 : 0, nullptr, 0};
   hipStream_t s = (hipStream_t)stream;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   const int lds_path = (K % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;
