@@ -27,6 +27,7 @@ def rup(a, b):
 
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
+FC_WGRAD_AT_END = os.environ.get("NPPC_FC_AT_END", "1") != "0"       # fc_output_layer weight gradient at the end of the main chain (A/B switch)
 COLSUM_IN_GEMM = os.environ.get("NPPC_COLSUM_IN_GEMM", "1") != "0"   # sconv bias gradients from the producing GEMM's epilogue (A/B switch)
 TN_PAIRED = os.environ.get("NPPC_TN_PAIRED", "1") != "0"              # one pass over the gate gradients per LSTM layer (A/B switch)
 FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "3"))    # 0: head kernels; 1: fused in the inference forward; 2: + training forward; 3: + backward
@@ -568,19 +569,23 @@ class FSNEngine:
                 self._side.wait_event(ev)
                 fn()
 
-        def fc_wgrad():
+        def fc_wgrad(slab):
             # parameter gradients only (bias: column sums; weight: two transposes + the NT split-K product -- F and C are not
-            # multiples of the TN kernel's tiles): off the main chain, which goes straight on to the input gradient
+            # multiples of the TN kernel's tiles)
             q = H.stream()
             H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, q)
             H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, q)
             H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, q)
-            self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab2, batch=3, sDst=sP)
+            self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab, batch=3, sDst=sP)
+        # bf16: the product waits until the END of the main chain -- the side queue (LSTM + TCN weight gradients) is the longer
+        # one, the main queue would idle ~0.4 ms in front of the join -- with a slab of its own (slab2 belongs to the side queue)
         # (the generic path below re-uses tA / tB / slab2 on the main stream: there the product stays in line)
-        if prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0:
-            on_side(fc_wgrad)
-        else:
-            fc_wgrad()
+        fc_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
+        fc_at_end = fc_ok and FC_WGRAD_AT_END
+        if fc_ok and not fc_at_end:
+            on_side(lambda: fc_wgrad(slab2))
+        elif not fc_ok:
+            fc_wgrad(slab2)
         # bf16: the 1x1-conv weight gradients run on the TN GEMM straight from the row-major activations (no transposes)
         tn_ok = prec == H.PREC_BF16 and TCN_HIDDEN % 128 == 0 and ldC % 64 == 0 and R % (64 * S2) == 0
         if tn_ok:
@@ -699,6 +704,8 @@ class FSNEngine:
                self.g(att + "feature_concate_fc.weight"), self.g(att + "feature_concate_fc.bias"),
                self.g(att + "fc1.weight"), self.g(att + "fc1.bias"), self.g(att + "fc2.weight"), self.g(att + "fc2.bias"),
                B, F, T, self.la, Tp, ldC, s)
+        if fc_at_end:
+            fc_wgrad(ws("slab_fc", (3 * S2 * Fr * ldC,), torch.float32))
         if self.defer_join:
             self.join_pending = True          # the caller joins (join_side) before anything reads the gradient
             FSNEngine._unjoined.add(id(self))
