@@ -713,6 +713,20 @@ class FSNEngine:
             torch.cuda.current_stream().wait_stream(self._side)       # join the weight-gradient stream
         return G
 
+    def side_stream(self):
+        return self._side
+
+    def prepack_on_side(self):
+        """re-pack the (just updated) weights on the side stream behind everything the current stream has been given so far;
+        the caller joins (join_side) before the packed copies are used and before the next cooperative LSTM launch"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            self.pack_weights()
+        self.join_pending = True
+        FSNEngine._unjoined.add(id(self))
+
     def join_side(self):
         """make the current stream wait for the side-stream weight gradients of the last backward (defer_join mode)"""
         if self.join_pending:

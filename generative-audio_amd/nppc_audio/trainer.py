@@ -155,6 +155,9 @@ class HipAdam(optim.Optimizer):
         return loss
 
 
+PREPACK_AFTER_UPDATE = os.environ.get("NPPC_PREPACK", "1") != "0"     # A/B switch (tools/diag)
+
+
 class FlatAdamStepper:
     """Fast path used by NPPCAudioTrainer.train: one Adam kernel over the direction net's flat parameter /
     gradient buffers, sharing state tensors with a HipAdam instance so checkpoints stay interchangeable."""
@@ -298,7 +301,7 @@ class NPPCAudioTrainer(nn.Module):
         if fast:
             self._pending = eng
             if not defer:
-                self.flush()
+                self._apply_pending(prepack=PREPACK_AFTER_UPDATE)
         else:
             mean_reduce_parameter_grads(net.parameters())
             self.optimizer.step()
@@ -306,17 +309,35 @@ class NPPCAudioTrainer(nn.Module):
         return reconst_err, objective, log
 
     def flush(self):
-        """apply a parked update now: join the weight-gradient stream, finish the gradient exchange, one Adam launch"""
+        """apply a parked update now (join the weight-gradient stream, finish the gradient exchange, one Adam launch) and join
+        whatever the last step left on the direction net's side stream: parameters AND streams are current afterwards"""
+        self._apply_pending(prepack=False)
+        eng = getattr(self.nppc_model.audio_pc_wrapper.net, "_engine", None)     # (no engine yet: nothing was launched)
+        if eng is not None and eng.join_pending:
+            reng = getattr(self.nppc_model.pretrained_restoration_model, "_engine", None)
+            if reng is not None:
+                reng.pre_lstm_hook = None
+            eng.join_side()
+
+    def _apply_pending(self, prepack):
         eng, self._pending = self._pending, None
         if eng is None:
             return
-        self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = None
+        reng = self.nppc_model.pretrained_restoration_model.engine()
+        reng.pre_lstm_hook = None
         eng.join_side()
         gflat = eng.fp.grad
         scale = self._reducer.finish(gflat)                  # sum over ranks; the mean's 1/W goes into Adam's grad scale
         if self._flat_adam is None or self._flat_adam.eng is not eng:
             self._flat_adam = FlatAdamStepper(self.optimizer, eng)
         self._flat_adam.step(gflat, scale)
+        if prepack and eng.side_stream() is not None:
+            # the bf16 / packed copies of the updated weights (0.2 ms of small launches at the top of the direction net's next
+            # forward, i.e. on the critical path between the two forward LSTMs) go out NOW on the side stream: they overlap
+            # the next minibatch's STFT and the frozen restorer's front, and are joined right before the restorer's LSTM
+            # launch (the cooperative kernels want the chip to themselves: FSNEngine._unjoined)
+            eng.prepack_on_side()
+            reng.pre_lstm_hook = eng.join_side
 
     def train(self, n_steps=None, n_epochs=None, checkpoint_dir="checkpoints", log_every=None):
         os.makedirs(checkpoint_dir, exist_ok=True)
