@@ -224,23 +224,48 @@ __global__ __launch_bounds__(256) void head_dy_gather_kernel(const float* __rest
 // D[bo] = sum_{t, fo, j < nfeat} dx[t][n][j] * x[t][n][j]      (x = normalised LSTM input as staged)
 // one workgroup per (frame, sample): rows of KX elements, of which the first nfeat count; 8 elements (one 16-byte load of
 // bf16) per thread and trip, only the ceil(nfeat / 8) chunks of a row that hold features are touched (scalar 2-byte loads
-// with a modulo per element ran at 0.65 TB/s: 417 us on the step's critical path right behind the LSTM backward)
+// with a modulo per element ran at 0.65 TB/s: 417 us on the step's critical path right behind the LSTM backward).
+// The same pass drops the three values of a row that the scatter pass needs -- dx[t][n][W + m], the gradients of the three
+// full-band features -- at their final place dpre[m][b][t][f] (raw): the scatter pass, which used to gather them with 2-byte
+// loads that touched every 128-byte row of dx a second time (133 MB for 6 MB), became an in-place pass over dpre.
 template <typename T>
 __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const T* __restrict__ dx, const T* __restrict__ x,
-                                                            double* __restrict__ D, int Fo, int KX, int nfeat, long Nseq) {
+                                                            double* __restrict__ D, T* __restrict__ dpre, int B, int Tp, int ldF,
+                                                            long strideFb, int W, int G, int Fo, int KX, int nfeat, long Nseq) {
   __shared__ double red[4];
   const int t = blockIdx.x, bo = blockIdx.y;
+  // sample b and drop-band group g of sequence block bo (the inverse of the scatter pass's b -> bo)
+  int g = 0, b = bo;
+  if (G > 1) {
+    int start = 0;
+    for (g = 0; g < G; ++g) {
+      const int cnt = (B - g + G - 1) / G;
+      if (bo < start + cnt) break;
+      start += cnt;
+    }
+    b = (bo - start) * G + g;
+  }
   const size_t base = ((size_t)t * Nseq + (size_t)bo * Fo) * KX;
+  const size_t orow = ((size_t)b * Tp + t) * ldF;
   const int cpr = (nfeat + 7) / 8;                         // chunks per row that hold features (KX % 8 == 0)
   float s = 0.f;
   for (int e = threadIdx.x; e < Fo * cpr; e += 256) {
     const int r = e / cpr, c = e % cpr;
-    float a[8], b[8];
+    float a[8], bb[8];
     load8<T>(dx + base + (size_t)r * KX + 8 * c, a);
-    load8<T>(x + base + (size_t)r * KX + 8 * c, b);
+    load8<T>(x + base + (size_t)r * KX + 8 * c, bb);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (8 * c + i < nfeat) s += a[i] * b[i];
+      if (8 * c + i < nfeat) s += a[i] * bb[i];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      if (c == (W + m) / 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i == (W + m) % 8) v = a[i];
+        dpre[(size_t)m * strideFb + orow + (size_t)r * G + g] = from_f32<T>(v);
+      }
   }
   const double d = wave_sum((double)s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
@@ -248,12 +273,12 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const T* __restrict_
   if (threadIdx.x == 0) atomicAdd(D + bo, red[0] + red[1] + red[2] + red[3]);
 }
 
-// dpre[m][b][t][f] = (fb[m][b][t][f] > 0) * ( sc_b * (kept ? dx[t][n][W+m] : 0) - sc_b * D[bo] / Nn )
+// in place: dpre[m][b][t][f] = (fb[m][b][t][f] > 0) * ( sc_b * (kept ? raw : 0) - sc_b * D[bo] / Nn ),  raw = dx[t][n][W+m] as
+// left by the reduce pass at the kept bins (the bins of other drop-band groups and the bins past Fo * G hold nothing: not read)
 template <typename T>
-__global__ __launch_bounds__(256) void sb_bwd_scatter_kernel(const T* __restrict__ dx, const T* __restrict__ fb,
-                                                             const float* __restrict__ scale, const double* __restrict__ D,
-                                                             T* __restrict__ dpre, int B, int F, int Tp, int ldF, long strideFb,
-                                                             int nb, int G, int Fo, int KX, long Nseq, double Nn) {
+__global__ __launch_bounds__(256) void sb_bwd_scatter_kernel(const T* __restrict__ fb, const float* __restrict__ scale,
+                                                             const double* __restrict__ D, T* __restrict__ dpre, int B, int F,
+                                                             int Tp, int ldF, long strideFb, int G, int Fo, double Nn) {
   const int t = blockIdx.x, b = blockIdx.y;
   int g = 0, bo = b;
   if (G > 1) {
@@ -264,19 +289,12 @@ __global__ __launch_bounds__(256) void sb_bwd_scatter_kernel(const T* __restrict
   }
   const float sc = scale[b];
   const float mterm = (float)((double)sc * D[bo] / Nn);
-  const int W = 2 * nb + 1;
   const size_t row = (size_t)b * Tp + t;
   for (int e = threadIdx.x; e < 3 * F; e += 256) {
     const int m = e / F, f = e % F;
-    float gv = 0.f;
-    bool kept = true;
-    int fo = f;
-    if (G > 1) {
-      kept = (f % G) == g && f < Fo * G;
-      fo = f / G;
-    }
-    if (kept) gv = to_f32<T>(dx[((size_t)t * Nseq + (size_t)bo * Fo + fo) * KX + W + m]);
     const size_t o = (size_t)m * strideFb + row * ldF + f;
+    const bool kept = G > 1 ? ((f % G) == g && f < Fo * G) : true;
+    const float gv = kept ? to_f32<T>(dpre[o]) : 0.f;
     const float v = to_f32<T>(fb[o]) > 0.f ? sc * gv - mterm : 0.f;
     dpre[o] = from_f32<T>(v);
   }
@@ -450,16 +468,18 @@ int nppc_subband_stage_bwd(int prec, const void* dx, const void* x, const void* 
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(D, 0, sizeof(double) * B, s) != hipSuccess) return NPPC_ELAUNCH;
   dim3 grid(Tv, B);
+  const int W = 2 * nb + 1;
+  if (W + 2 >= nfeat) return NPPC_EBADARG;
   if (prec == NPPC_PREC_BF16) {
-    hipLaunchKernelGGL(sb_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dx, (const bf16_t*)x, D, Fo, KX,
-                       nfeat, Nseq);
-    hipLaunchKernelGGL(sb_bwd_scatter_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dx, (const bf16_t*)fb, scale, D,
-                       (bf16_t*)dpre, B, F, Tp, ldF, strideFb, nb, Geff, Fo, KX, Nseq, Nn);
+    hipLaunchKernelGGL(sb_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dx, (const bf16_t*)x, D, (bf16_t*)dpre, B,
+                       Tp, ldF, strideFb, W, Geff, Fo, KX, nfeat, Nseq);
+    hipLaunchKernelGGL(sb_bwd_scatter_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)fb, scale, D, (bf16_t*)dpre, B, F, Tp,
+                       ldF, strideFb, Geff, Fo, Nn);
   } else {
-    hipLaunchKernelGGL(sb_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)x, D, Fo, KX, nfeat,
-                       Nseq);
-    hipLaunchKernelGGL(sb_bwd_scatter_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)fb, scale, D,
-                       (float*)dpre, B, F, Tp, ldF, strideFb, nb, Geff, Fo, KX, Nseq, Nn);
+    hipLaunchKernelGGL(sb_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)x, D, (float*)dpre, B, Tp,
+                       ldF, strideFb, W, Geff, Fo, KX, nfeat, Nseq);
+    hipLaunchKernelGGL(sb_bwd_scatter_kernel<float>, grid, dim3(256), 0, s, (const float*)fb, scale, D, (float*)dpre, B, F, Tp, ldF,
+                       strideFb, Geff, Fo, Nn);
   }
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
