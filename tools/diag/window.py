@@ -22,7 +22,15 @@ last = big[3] if len(big) > 3 else len(step) - 1
 tail = step[big[2] + 1:last]
 print(f"--- LSTM backward end -> next restorer LSTM start: {(int(step[last]['Start_Timestamp']) - int(step[big[2]]['End_Timestamp'])) / 1e3:.1f} us wall, {len(tail)} kernels")
 main_q = step[big[2]]['Queue_Id']
-front = [r for r in tail if r['Queue_Id'] == main_q][-40:]
+mq = [r for r in tail if r['Queue_Id'] == main_q]
+print("  (first 45 and last 40 launches of the main queue)")
+prev = int(step[big[2]]['End_Timestamp'])
+for r in mq[:45]:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    print(f"  q{r['Queue_Id']} +{(s - prev) / 1e3:6.1f} gap  {(e - s) / 1e3:7.1f} us  {name(r)}")
+    prev = max(prev, e)
+print("  ...")
+front = mq[-40:]
 prev = int(front[0]['Start_Timestamp'])
 for r in front:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
