@@ -1,0 +1,505 @@
+// Weight-STATIONARY cluster forward of the fused 2-layer LSTM (bf16, H = 384, input <= 64 columns):
+// nn.LSTM(34, 384, num_layers=2) of audio_zen/model/module/sequence_model.py:113-123 for N independent sequences.
+//
+// The streaming kernels (lstm.hip, lstm_coop.hip) re-read their weight slice from L2 on every time step and are bound by
+// that stream plus ~20 us of fixed per-step cost.  Here a cluster of 12 CUs holds ALL 3.7 MB of weights in REGISTERS for
+// the whole launch: CU `cu` owns hidden units [32 cu, 32 cu + 32) of both layers; inside it waves 0-3 own 8 units each of
+// layer 1 (28 k-steps x 4 VGPRs of A fragments) and waves 4-7 the same units of layer 2 (48 k-steps x 4 VGPRs = 192 of
+// the 256 registers a wave has at two waves per SIMD).  The product is TRANSPOSED with respect to the streaming kernels:
+// the MFMA A operand is the weight block [32 gate rows = 8 units x (i,g,f,o)][16 k], the B operand the activations
+// [16 k][32 sequences], so a lane of the 32x32 accumulator holds the four gates of four units of ONE sequence and the
+// cell update needs no cross-lane traffic.
+//
+// What moves instead of weights is the hidden state: a cluster walks its sequences in chunks of 32, round robin, and
+// every CU gathers the full [x_s | h1_{s-1} | h2_{s-2}] tile of a chunk (32 x 832 bf16 = 52 KB) into LDS.  One item
+// (chunk c, fused step s) computes layer 1 of time s AND layer 2 of time s-1 from that ONE tile (both only need h1_{s-1}
+// and older state), so there is one hand-off per time step, not two, and h1 is gathered once.  A CU publishes 2 x 2 KB per
+// item (its 32 units of h1_s and h2_{s-1}); the consumer of those bytes is item (c, s+1), nch - 1 items later: the
+// hand-off latency is hidden by the other chunks of the cluster as long as nch >= ~4.
+//
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, recipe R1; MI355X_MICROARCH visibility table, row 1):
+//   producer: every payload store is a 16-byte write-through (sc1) buffer store; one item LATER every wave passes a counted
+//             s_waitcnt that covers those stores, then the workgroup barrier, then ONE lane stores the chunk's epoch flag
+//             (relaxed, agent scope).
+//   consumer: each staging wave polls the 12 flags of the chunk (one sc1 load instruction, bounded spin) and only then
+//             issues its sc1 buffer loads of the payload.
+// Results never depend on placement or dispatch order; what must hold is co-residency of a cluster's 12 workgroups, which
+// the launcher guarantees (one workgroup per CU: > 80 KB of LDS, grid <= CU count, occupancy checked).  Every spin is
+// bounded; a time-out adds 1 to the sticky counter behind the flag words (same contract as lstm_coop.hip).
+#include "common.h"
+#include "nppc_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned char lds_u8;   // LDS bytes (the compiler infers the address space from `smem`)
+
+constexpr int WS_H = 384, WS_G = 12, WS_UC = 32, WS_KX = 64, WS_MC = 32, WS_NT = 512;
+constexpr int WS_NK1 = (WS_KX + WS_H) / 16;              // 28 k-steps of 16: [x | h1]
+constexpr int WS_NK2 = 2 * WS_H / 16;                    // 48 k-steps: [h1 | h2]
+constexpr int WS_ROWB = (WS_KX + 2 * WS_H) * 2 + 16;     // 1680 bytes per tile row: odd multiple of 16 -> conflict-free b128 reads
+constexpr int WS_TILEB = WS_MC * WS_ROWB;                // 53760
+constexpr int WS_OFF_BIAS = 2 * WS_TILEB;                // [2 layers][32 units][4 gates (i,g,f,o)] fp32
+constexpr int WS_OFF_WH = WS_OFF_BIAS + 2 * WS_UC * 16;  // head weights as 16x16x32 A fragments [12 kk][64 lanes][8] bf16
+constexpr int WS_SMEM = WS_OFF_WH + 12 * 64 * 16;
+constexpr int WS_HB = WS_H * 2;                          // bytes of one h row
+constexpr unsigned WS_SPIN_LIMIT = 1u << 22;
+static_assert(WS_SMEM > 80 * 1024 && WS_SMEM <= 160 * 1024, "one workgroup per CU");
+
+struct WsArgs {
+  const void* x;        // [Tn][N][64] bf16
+  const void* wp1;      // [12 cu][4 ug][28][64 lanes][8] bf16   (lstm_ws_pack_kernel)
+  const void* wp2;      // [12 cu][4 ug][48][64 lanes][8]
+  const float* bias1;   // [4][H] torch gate order (i,f,g,o), b_ih + b_hh
+  const float* bias2;
+  void* h1; void* h2;   // TRAIN: [Tn][N][H] (saved state AND exchange medium); else rings [2][N][H]
+  void* g1; void* g2;   // TRAIN: [Tn][N][H][4] (i,g,f,o)
+  void* c1; void* c2;   // TRAIN: [Tn][N][H]
+  float* cst;           // fp32 cell state [clusters][12 cu][nch_max][2 layers][4 ug][64 lanes][4]
+  unsigned* flags;      // [clusters][nch_max][16] epochs (zeroed by the launcher), then the sticky time-out counter
+  const void* whp;      // head weights [16][H] bf16 row-major (rows >= O zero); nullptr: no head
+  float* hpart;         // [Tn][N][O] fp32 head sums (bias and re-layout: nppc_sb_head_finalize with G = 1)
+  long N; int Tn; int O; int clusters; int nch_max; int nchunks;
+};
+
+// workgroup -> (cluster, cu).  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the blocks that share one); with the
+// full grid of 256 the first 24 blocks of every XCD form two whole clusters (their gather re-reads hit that XCD's L2) and
+// the remaining 8 per XCD are pooled into five more.  Placement is a speed matter only.
+__device__ __forceinline__ bool ws_ids(int clusters, int& cluster, int& cu) {
+  const int b = blockIdx.x;
+  if (gridDim.x == 256) {
+    const int xcd = b & 7, slot = b >> 3;
+    if (slot < 24) {
+      cluster = xcd * 2 + slot / WS_G;
+      cu = slot % WS_G;
+    } else {
+      const int p = xcd * 8 + slot - 24;
+      cluster = 16 + p / WS_G;
+      cu = p % WS_G;
+    }
+  } else {
+    cluster = b / WS_G;
+    cu = b % WS_G;
+  }
+  return cluster < clusters;
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+// LDS-only workgroup barrier: does not drain the wave's global stores (the publish stores of THIS item stay in flight)
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct WsItem {
+  int s, c;             // fused step, local chunk
+  long row0;            // first sequence of the chunk
+};
+
+// per-time-slot buffer descriptor: base + slot * N * row_bytes, N * row_bytes records (rows >= N and invalid times: range
+// check drops stores and returns zeros for loads)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base, long slot, long N, int row_bytes, bool valid) {
+  const char* p = reinterpret_cast<const char*>(base) + (size_t)slot * N * row_bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, valid ? (unsigned)(N * row_bytes) : 0u, 0x00020000);
+}
+
+// cell update of one layer for this lane's 4 units x 1 sequence.  acc[4m + g]: unit m, gate g in (i, g, f, o).
+template <bool TRAIN>
+__device__ __forceinline__ void ws_cell(const f32x16& acc, f32x4& c, unsigned (&hpk)[2], u32x4 (&gpk)[2], unsigned (&cpk)[2]) {
+  float hv[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float iv = sigmoid_f(acc[4 * m + 0]);
+    const float gv = tanh_f(acc[4 * m + 1]);
+    const float fv = sigmoid_f(acc[4 * m + 2]);
+    const float ov = sigmoid_f(acc[4 * m + 3]);
+    const float cn = fv * c[m] + iv * gv;
+    c[m] = cn;
+    hv[m] = ov * tanh_f(cn);
+    if (TRAIN) {
+      gpk[m >> 1][2 * (m & 1)] = pack2(iv, gv);
+      gpk[m >> 1][2 * (m & 1) + 1] = pack2(fv, ov);
+    }
+  }
+  hpk[0] = pack2(hv[0], hv[1]);
+  hpk[1] = pack2(hv[2], hv[3]);
+  if (TRAIN) {
+    cpk[0] = pack2(c[0], c[1]);
+    cpk[1] = pack2(c[2], c[3]);
+  }
+}
+
+// the 8 units of a sequence sit in two lanes (l: units 0-3, l + 32: units 4-7): bring both halves into the lower lane
+__device__ __forceinline__ u32x4 ws_join(const unsigned (&hpk)[2]) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(hpk[0], hpk[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(hpk[1], hpk[1], false, false);
+  return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int cluster, cu;
+  if (!ws_ids(a.clusters, cluster, cu)) return;
+  const int nch = (a.nchunks - cluster + a.clusters - 1) / a.clusters;   // chunks cluster, cluster + clusters, ...
+  if (nch <= 0) return;
+  const int layer = wave >> 2, ug = wave & 3;
+  const long N = a.N;
+  const int Tn = a.Tn;
+  const int nsteps = Tn + (a.whp ? 2 : 1);
+  const int nitems = nch * nsteps;
+  const int seq = lane & 31, hh = lane >> 5;
+  const int unit0 = cu * WS_UC + ug * 8 + 4 * hh;          // this lane's 4 units
+
+  // ---- one-time LDS set-up: biases of the own 32 units, head weights as A fragments
+  {
+    float* bl = reinterpret_cast<float*>(smem + WS_OFF_BIAS);
+    for (int e = tid; e < 2 * WS_UC * 4; e += WS_NT) {
+      const int g = e & 3, u = (e >> 2) % WS_UC, l = e / (4 * WS_UC);
+      const int tg = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 3));
+      bl[e] = (l ? a.bias2 : a.bias1)[tg * WS_H + cu * WS_UC + u];
+    }
+    if (a.whp) {
+      const bf16_t* wh = reinterpret_cast<const bf16_t*>(a.whp);
+      for (int e = tid; e < 12 * 64; e += WS_NT) {
+        const int kk = e >> 6, l = e & 63;
+        *reinterpret_cast<u32x4*>(smem + WS_OFF_WH + e * 16) =
+            *reinterpret_cast<const u32x4*>(wh + (size_t)(l & 15) * WS_H + 32 * kk + 8 * (l >> 4));
+      }
+    }
+  }
+  gu32* flags = (gu32*)(a.flags + (size_t)cluster * a.nch_max * 16);
+  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * a.nch_max * 16);
+  const lds_u8* ltile = reinterpret_cast<const lds_u8*>(smem);
+  // B fragment (activations) of this lane: row seq, k = 8 hh + j of each 16-wide k-step
+  const int boff = seq * WS_ROWB + hh * 16 + (layer ? WS_KX * 2 : 0);
+  float* cst = a.cst + (((size_t)cluster * WS_G + cu) * a.nch_max * 2 + layer) * 4 * 256 + ug * 256 + lane * 4;   // + c * 2*4*256
+
+  auto mk_item = [&](int s_, int c_) {
+    WsItem it;
+    it.s = s_;
+    it.c = c_;
+    it.row0 = (long)(cluster + (long)c_ * a.clusters) * WS_MC;
+    return it;
+  };
+  auto next_item = [&](const WsItem& it) { return it.c + 1 < nch ? mk_item(it.s, it.c + 1) : mk_item(it.s + 1, 0); };
+  auto slot = [&](int t) -> long { return TRAIN ? t : (t & 1); };
+  // fp32 cell state of (chunk, layer, unit group): 16 bytes per lane, private to this wave (plain, L2-resident)
+  auto cst_of = [&](const WsItem& it) { return cst + (size_t)it.c * 2 * 4 * 256; };
+
+  if (layer == 0) {
+    // =============================== layer-1 waves: staging + layer 1 + head ===============================
+    bf16x8 w[WS_NK1];
+    {
+      const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.wp1) + ((size_t)(cu * 4 + ug) * WS_NK1) * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < WS_NK1; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
+      __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): no per-item waits for the weight loads
+    }
+    // staging pattern: waves 0,1 gather h1 rows [16 (ug & 1), +16), waves 2,3 the same rows of h2: 768 16-byte chunks =
+    // 12 per lane, chunk idx = lane + 64 j -> (row idx / 48, column idx % 48); the pattern repeats every 3 j with 4 rows more
+    int sv[3], dv[3];
+#pragma unroll
+    for (int jm = 0; jm < 3; ++jm) {
+      const int idx = lane + 64 * jm;
+      sv[jm] = (idx / 48) * WS_HB + (idx % 48) * 16;
+      dv[jm] = (16 * (ug & 1) + idx / 48) * WS_ROWB + WS_KX * 2 + (ug >> 1) * WS_HB + (idx % 48) * 16;
+    }
+    const int xdv = (8 * ug + (lane >> 3)) * WS_ROWB + (lane & 7) * 16;
+
+    u32x4 st[13];
+    // gather of item `it` (no poll here: wave 4 has seen the flags of this item before the barrier this wave has passed)
+    auto stage_issue = [&](const WsItem& it) {
+      const int th = (ug >> 1) ? it.s - 2 : it.s - 1;              // time of the h rows this wave gathers
+      const __amdgpu_buffer_rsrc_t hr = ws_rsrc((ug >> 1) ? a.h2 : a.h1, slot(th), N, WS_HB, th >= 0 && th < Tn);
+      const int so = (int)(it.row0 + 16 * (ug & 1)) * WS_HB;
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+        st[j] = __builtin_amdgcn_raw_buffer_load_b128(hr, sv[j % 3], so + (j / 3) * 4 * WS_HB, 16);
+      const __amdgpu_buffer_rsrc_t xr = ws_rsrc(a.x, it.s, N, WS_KX * 2, it.s < Tn);
+      st[12] = __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, (int)(it.row0 + 8 * ug) * WS_KX * 2, 0);
+    };
+    auto stage_write = [&](int buf) {
+      unsigned char* t = smem + buf * WS_TILEB;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) *reinterpret_cast<u32x4*>(t + dv[j % 3] + (j / 3) * 4 * WS_ROWB) = st[j];
+      *reinterpret_cast<u32x4*>(t + xdv) = st[12];
+    };
+
+    __syncthreads();                                               // biases / head weights in LDS
+    WsItem it = mk_item(0, 0), itn = next_item(it), itp = it;
+    stage_issue(it);
+    stage_write(0);
+    f32x4 cc = {0.f, 0.f, 0.f, 0.f};                               // cell state of the current item (s = 0: zero)
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < nitems; ++i) {
+      const int buf = i & 1;
+      const bool more = i + 1 < nitems;
+      // ---- head of time s - 2 from the full h2_{s-2} in the tile: waves 2, 3 of the chunk's designated CU.  FIRST in the
+      // iteration: its (conditional) stores must be older than the gather below, so that the waits for the gather can be
+      // counted ones that leave this item's unconditional stores in flight
+      if (a.whp && ug >= 2 && it.s >= 2 && (it.c + it.s) % WS_G == cu) {
+        const int n16 = lane & 15, q = lane >> 4, half = ug - 2;
+        const lds_u8* bp = ltile + buf * WS_TILEB + (16 * half + n16) * WS_ROWB + (WS_KX + WS_H) * 2 + q * 16;
+        const lds_u8* ap = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_WH + lane * 16;
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk)
+          hacc = mma16(*reinterpret_cast<const bf16x8*>(ap + kk * 1024), *reinterpret_cast<const bf16x8*>(bp + kk * 64), hacc);
+        float* hp = a.hpart + ((size_t)(it.s - 2) * N + it.row0 + 16 * half + n16) * a.O;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * q + j < a.O) __builtin_nontemporal_store(hacc[j], hp + 4 * q + j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // next item's cell state (older than everything below: waiting for it never waits for this item's stores), then the
+      // next item's gather
+      f32x4 ccn = *reinterpret_cast<const f32x4*>(cst_of(itn));
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) stage_issue(itn);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // ---- layer 1 of time s: gates = W1 . [x_s | h1_{s-1}]^T + b.  Executed for EVERY item (the steps behind the last
+        // time step compute on zeros and store through an empty descriptor): no store sits in a conditional path
+        const bool act = it.s < Tn;
+        f32x16 acc;
+        {
+          const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (ug * 8 + 4 * hh) * 16;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
+            acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+          }
+        }
+        const lds_u8* bp = ltile + buf * WS_TILEB + boff;
+#pragma unroll
+        for (int ks = 0; ks < WS_NK1; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], *reinterpret_cast<const bf16x8*>(bp + ks * 32), acc, 0, 0, 0);
+        unsigned hpk[2], cpk[2];
+        u32x4 gpk[2];
+        if (it.s == 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
+        ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
+        *reinterpret_cast<f32x4*>(cst_of(it)) = cc;
+        const u32x4 hj = ws_join(hpk);
+        const int roff = (int)(it.row0 + seq);
+        if (TRAIN) {
+          const __amdgpu_buffer_rsrc_t gr = ws_rsrc(a.g1, it.s, N, WS_H * 8, act);
+          const __amdgpu_buffer_rsrc_t cr = ws_rsrc(a.c1, it.s, N, WS_HB, act);
+          __builtin_amdgcn_raw_buffer_store_b128(gpk[0], gr, roff * (WS_H * 8) + unit0 * 8, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(gpk[1], gr, roff * (WS_H * 8) + unit0 * 8 + 16, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{cpk[0], cpk[1]}, cr, roff * WS_HB + unit0 * 2, 0, 2);
+        }
+        const __amdgpu_buffer_rsrc_t hr = ws_rsrc(a.h1, slot(it.s), N, WS_HB, act);
+        // lanes 32-63 hold copies: their offset is out of range, the store is dropped (no branch around the store)
+        __builtin_amdgcn_raw_buffer_store_b128(hj, hr, lane < 32 ? roff * WS_HB + (cu * WS_UC + ug * 8) * 2 : 0x7ffffff0, 0, 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // every store of item i - 1 is complete once this wait for the gather has passed: the gather was issued behind them and
+      // a wave's vector-memory operations retire in order
+      if (more) stage_write(buf ^ 1);
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      cc = ccn;                                                    // (the wait for ccn is older still)
+      ws_barrier();
+      if (tid == 0 && i >= 1)
+        __hip_atomic_store(flags + itp.c * 16 + cu, (unsigned)(itp.s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      itp = it;
+      it = itn;
+      itn = next_item(itn);
+    }
+  } else {
+    // =============================== layer-2 waves (wave 4 also polls) ===============================
+    bf16x8 w[WS_NK2];
+    {
+      const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.wp2) + ((size_t)(cu * 4 + ug) * WS_NK2) * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < WS_NK2; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __syncthreads();
+    WsItem it = mk_item(0, 0), itn = next_item(it), it2 = next_item(itn);
+    f32x4 cc = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < nitems; ++i) {
+      const int buf = i & 1;
+      f32x4 ccn = *reinterpret_cast<const f32x4*>(cst_of(itn));
+      // wave 4: the flags of item i + 2 (its gather starts right behind this iteration's barrier): requested here, looked
+      // at behind the GEMM.  Every CU of the cluster must have published item (c, s - 1).
+      const bool polls = ug == 0 && i + 2 < nitems && it2.s >= 1;
+      unsigned pv = 0xffffffffu;
+      if (polls && lane < WS_G) pv = __hip_atomic_load(flags + it2.c * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool active = it.s >= 1 && it.s <= Tn;
+      {
+        // ---- layer 2 of time s - 1: gates = W2 . [h1_{s-1} | h2_{s-2}]^T + b (every item: see layer 1)
+        const int t = it.s - 1;
+        f32x16 acc;
+        {
+          const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (WS_UC + ug * 8 + 4 * hh) * 16;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
+            acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+          }
+        }
+        const lds_u8* bp = ltile + buf * WS_TILEB + boff;
+#pragma unroll
+        for (int ks = 0; ks < WS_NK2; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], *reinterpret_cast<const bf16x8*>(bp + ks * 32), acc, 0, 0, 0);
+        unsigned hpk[2], cpk[2];
+        u32x4 gpk[2];
+        if (t <= 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
+        ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
+        *reinterpret_cast<f32x4*>(cst_of(it)) = cc;
+        const u32x4 hj = ws_join(hpk);
+        const int roff = (int)(it.row0 + seq);
+        if (TRAIN) {
+          const __amdgpu_buffer_rsrc_t gr = ws_rsrc(a.g2, t, N, WS_H * 8, active);
+          const __amdgpu_buffer_rsrc_t cr = ws_rsrc(a.c2, t, N, WS_HB, active);
+          __builtin_amdgcn_raw_buffer_store_b128(gpk[0], gr, roff * (WS_H * 8) + unit0 * 8, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(gpk[1], gr, roff * (WS_H * 8) + unit0 * 8 + 16, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{cpk[0], cpk[1]}, cr, roff * WS_HB + unit0 * 2, 0, 2);
+        }
+        const __amdgpu_buffer_rsrc_t hr = ws_rsrc(a.h2, slot(t), N, WS_HB, active);
+        __builtin_amdgcn_raw_buffer_store_b128(hj, hr, lane < 32 ? roff * WS_HB + (cu * WS_UC + ug * 8) * 2 : 0x7ffffff0, 0, 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (polls) {
+        unsigned spins = 0;
+        while (__builtin_amdgcn_ballot_w64(pv < (unsigned)it2.s) != 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > WS_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          if (lane < WS_G) pv = __hip_atomic_load(flags + it2.c * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only: the payload loads are sc1
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // every store of item i - 1 must be complete before this barrier (the flag of item i - 1 is raised behind it): leave
+      // only THIS item's stores in flight
+      if (TRAIN) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      cc = ccn;
+      ws_barrier();
+      it = itn;
+      itn = it2;
+      it2 = next_item(it2);
+    }
+  }
+}
+
+// packed A fragments: element (cu, ug, ks, lane l, j): gate row r = l & 31 -> unit index r >> 2 = 2 m + hh' (the accumulator
+// row map of the 32x32 MFMA), local unit = 4 hh' + m, gate g = r & 3 in (i,g,f,o); k = 16 ks + 8 (l >> 5) + j
+//   layer 1: k < 64 -> W_ih[row][k] (0 for k >= I), else W_hh[row][k - 64]
+//   layer 2: k < 384 -> W_ih[row][k] (input h1), else W_hh[row][k - 384]
+__global__ void lstm_ws_pack_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, bf16_t* __restrict__ out, int I,
+                                    int layer) {
+  const int nk = layer == 1 ? WS_NK1 : WS_NK2;
+  const size_t total = (size_t)WS_G * 4 * nk * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = e & 7, l = (e >> 3) & 63;
+    size_t f = e >> 9;
+    const int ks = f % nk; f /= nk;
+    const int ug = f & 3;
+    const int cu = (int)(f >> 2);
+    const int r = l & 31, g = r & 3, ui = r >> 2;
+    const int ul = 4 * (ui & 1) + (ui >> 1);
+    const int tg = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 3));
+    const int row = tg * WS_H + cu * WS_UC + ug * 8 + ul;
+    const int k = 16 * ks + 8 * (l >> 5) + j;
+    float v;
+    if (layer == 1) v = k < WS_KX ? (k < I ? w_ih[(size_t)row * I + k] : 0.f) : w_hh[(size_t)row * WS_H + (k - WS_KX)];
+    else v = k < WS_H ? w_ih[(size_t)row * WS_H + k] : w_hh[(size_t)row * WS_H + (k - WS_H)];
+    out[e] = f2bf(v);
+  }
+}
+
+static int ws_fits(const void* kernel, int& per_cu_cache, int& n_cu) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NPPC_ELAUNCH;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return NPPC_ELAUNCH;
+  }
+  n_cu = ncu;
+  if (per_cu_cache < 0 &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cache, kernel, WS_NT, WS_SMEM) != hipSuccess)
+    return NPPC_ELAUNCH;
+  return per_cu_cache >= 1 ? NPPC_OK : NPPC_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Plan of the weight-stationary forward for N sequences: clusters of 12 CUs and the largest number of 32-sequence chunks
+// one cluster walks; 0 clusters = not applicable (the caller uses the streaming kernels).  Needs whole chunks (N % 32 == 0)
+// and at least 4 chunks per cluster: the flag of item (c, s) is raised one item late and polled two items early, so with
+// fewer chunks a cluster would wait for itself.
+int nppc_lstm2_ws_plan(int prec, long N, int H, int I, int n_cu, int* clusters, int* nch_max) {
+  *clusters = 0; *nch_max = 0;
+  if (prec != NPPC_PREC_BF16 || H != WS_H || I > WS_KX || N <= 0 || N % WS_MC) return NPPC_OK;
+  const long nchunks = N / WS_MC;
+  long cl = n_cu / WS_G;
+  if (cl > nchunks / 4) cl = nchunks / 4;
+  if (cl < 1) return NPPC_OK;
+  *clusters = (int)cl;
+  *nch_max = (int)((nchunks + cl - 1) / cl);
+  return NPPC_OK;
+}
+
+int nppc_lstm2_ws_packed_elems(long* n1, long* n2) {
+  *n1 = (long)WS_G * 4 * WS_NK1 * 512;
+  *n2 = (long)WS_G * 4 * WS_NK2 * 512;
+  return NPPC_OK;
+}
+
+int nppc_lstm2_ws_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wp1, void* wp2,
+                       void* stream) {
+  if (!w_ih0 || !w_hh0 || !w_ih1 || !w_hh1 || !wp1 || !wp2 || I > WS_KX) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_ws_pack_kernel, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (bf16_t*)wp1, I, 1);
+  hipLaunchKernelGGL(lstm_ws_pack_kernel, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (bf16_t*)wp2, WS_H, 2);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// Weight-stationary forward.  train = 0: h1 / h2 are [2][N][H] exchange rings, g / c unused; train = 1: h1 / h2 / g1 / g2 /
+// c1 / c2 are the saved state in the layouts of nppc_lstm2_fwd.  cst: clusters * 12 * nch_max * 2048 floats; flags: clusters *
+// nch_max * 16 + 4 u32 (epochs zeroed here, the sticky time-out counter is word clusters * nch_max * 16).  whp / hpart / O:
+// fused output head (hpart [Tn][N][O] fp32 without bias), or whp = nullptr.
+int nppc_lstm2_fwd_ws(int train, const void* x, const void* wp1, const void* wp2, const float* bias1, const float* bias2, void* h1,
+                      void* h2, void* g1, void* g2, void* c1, void* c2, float* cst, unsigned* flags, const void* whp, float* hpart,
+                      int O, long N, int Tn, int clusters, int nch_max, void* stream) {
+  if (!x || !wp1 || !wp2 || !bias1 || !bias2 || !h1 || !h2 || !cst || !flags || N <= 0 || Tn <= 0 || clusters < 1 || nch_max < 1)
+    return NPPC_EBADARG;
+  if (train && (!g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
+  if (whp && (!hpart || O < 1 || O > 16)) return NPPC_EBADARG;
+  if (N % WS_MC) return NPPC_EUNSUPPORTED;
+  const long nchunks = N / WS_MC;
+  if ((long)clusters * nch_max < nchunks || nchunks / clusters < 4 || N * (long)WS_H * 8 >= (1l << 31)) return NPPC_EBADARG;
+  WsArgs a{x, wp1, wp2, bias1, bias2, h1, h2, g1, g2, c1, c2, cst, flags, whp, hpart, N, Tn, O, clusters, nch_max, (int)nchunks};
+  hipStream_t s = (hipStream_t)stream;
+  const void* k = train ? reinterpret_cast<const void*>(lstm2_ws_fwd_kernel<true>)
+                        : reinterpret_cast<const void*>(lstm2_ws_fwd_kernel<false>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM) != hipSuccess) return NPPC_ELAUNCH;
+  static int per_cu[2] = {-1, -1};
+  int n_cu = 0;
+  const int fits = ws_fits(k, per_cu[train ? 1 : 0], n_cu);
+  if (fits != NPPC_OK) return fits;
+  if (clusters * WS_G > n_cu) return NPPC_EUNSUPPORTED;         // every workgroup of a cluster must be resident
+  if (hipMemsetAsync(flags, 0, (size_t)clusters * nch_max * 16 * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  const int grid = n_cu == 256 ? 256 : clusters * WS_G;
+  if (train) hipLaunchKernelGGL(lstm2_ws_fwd_kernel<true>, dim3(grid), dim3(WS_NT), WS_SMEM, s, a);
+  else hipLaunchKernelGGL(lstm2_ws_fwd_kernel<false>, dim3(grid), dim3(WS_NT), WS_SMEM, s, a);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+}  // extern "C"

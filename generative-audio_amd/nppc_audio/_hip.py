@@ -86,6 +86,10 @@ SIGS = {
     "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P],
     "nppc_lstm2_fwd_coop_head": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P, P, I, P],
     "nppc_sb_head_finalize": [P, I, P, P, L, I, I, I, I, P],
+    "nppc_lstm2_ws_plan": [I, L, I, I, I, PI, PI],
+    "nppc_lstm2_ws_packed_elems": [PL, PL],
+    "nppc_lstm2_ws_pack": [P, P, P, P, I, P, P, P],
+    "nppc_lstm2_fwd_ws": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, I, P],
     "nppc_lstm2_coop_bwd_packed_elems": [PL],
     "nppc_lstm2_coop_bwd_pack": [P, P, P, P, I, P, P, P],
     "nppc_lstm2_bwd_coop": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],

@@ -336,7 +336,7 @@ class FSNEngine:
         # 8: Linear(H -> O) + re-layout + look-ahead crop
         out = torch.empty(B, self.O, d["Fo"], T, dtype=torch.float32, device=self.dev)
         if "head_partial" in lo:
-            H.call("nppc_sb_head_finalize", lo["head_partial"], 2, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
+            H.call("nppc_sb_head_finalize", lo["head_partial"], lo["head_partial"].shape[0], self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,
                    self.la, self.O, d["Fo"], s)
         else:
             H.call("nppc_sb_head", prec, lo["h2"], self.Whp, self.p("sb_model.fc_output_layer.bias"), out, d["Nseq"], Tv,

@@ -35,12 +35,21 @@ class PackedLSTM:
         self.wp2 = torch.empty(n2.value, dtype=dt, device=device)
         self.bias1 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
         self.bias2 = torch.empty(4 * Hd, dtype=torch.float32, device=device)
+        # weight-stationary cluster kernel (csrc/lstm_ws.hip): its own A-fragment packing of the same weights
+        self.ws = prec == H.PREC_BF16 and Hd == 384 and I <= 64
+        if self.ws:
+            m1, m2 = ctypes.c_long(), ctypes.c_long()
+            H.call("nppc_lstm2_ws_packed_elems", ctypes.byref(m1), ctypes.byref(m2))
+            self.wsp1 = torch.empty(m1.value, dtype=dt, device=device)
+            self.wsp2 = torch.empty(m2.value, dtype=dt, device=device)
         own_workspaces(self)
 
     def pack(self, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
         ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1)]
         H.call("nppc_lstm2_pack_weights", self.prec, *ws, self.I, self.Hd, self.wp1, self.wp2, self.bias1,
                self.bias2, H.stream())
+        if self.ws:
+            H.call("nppc_lstm2_ws_pack", ws[0], ws[1], ws[4], ws[5], self.I, self.wsp1, self.wsp2, H.stream())
         return self
 
 
@@ -56,6 +65,7 @@ def pick_mtile(n_seq, prec, train, n_cu=256):
 
 _WS = {}
 COOP = True          # use the cooperative (weights split over CU pairs) kernels when the shape allows it
+WS = os.environ.get("NPPC_LSTM_WS", "1") != "0"    # weight-stationary 12-CU clusters for the forward when the plan allows
 N_CU = None
 
 
@@ -172,6 +182,12 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
+    if mtile == "ws" or (WS and COOP and mtile is None):
+        ws_out = _lstm2_forward_ws(x_tm, packed, train, head, out, tag)
+        if ws_out is not None:
+            return ws_out
+        assert mtile != "ws", "the weight-stationary plan does not apply to this shape"
+        mtile = None
     if (COOP and mtile is None) or isinstance(mtile, tuple):
         G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if isinstance(mtile, tuple):               # (G, mtile) forced by a test / benchmark
@@ -209,6 +225,42 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         "nppc_lstm2_fwd", packed.prec, int(train), mtile, x_tm, packed.wp1, packed.wp2, packed.bias1, packed.bias2,
         out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
         H.stream()))
+    return out
+
+
+def ws_plan(N, packed):
+    """(clusters, nch_max) of the weight-stationary forward for N sequences, or None"""
+    if not getattr(packed, "ws", False):
+        return None
+    cl, nch = ctypes.c_int(), ctypes.c_int()
+    H.call("nppc_lstm2_ws_plan", packed.prec, N, packed.Hd, packed.I, _n_cu(), ctypes.byref(cl), ctypes.byref(nch))
+    return (cl.value, nch.value) if cl.value > 0 else None
+
+
+def _lstm2_forward_ws(x_tm, packed, train, head, out, tag):
+    """weight-stationary cluster forward (csrc/lstm_ws.hip).  Inference needs the fused head (h2 only lives in a two-slot
+    exchange ring); training keeps the whole saved state and takes the head along when asked.  Returns None when the
+    plan does not apply."""
+    Tn, N, _ = x_tm.shape
+    plan = ws_plan(N, packed)
+    if plan is None or (not train and head is None) or (head is not None and head[1] > FUSED_HEAD_MAX_O):
+        return None
+    ncl, nch = plan
+    dt, dev, Hd = x_tm.dtype, x_tm.device, packed.Hd
+    cst = workspace(tag + ("ws_cst",), (ncl * 12 * nch * 2048,), torch.float32, dev)
+    flags = workspace(tag + ("ws", "coop_flags"), (ncl * nch * 16 + 4,), torch.int32, dev, zero=True)
+    if train:
+        h1, h2 = out["h1"], out["h2"]
+    else:
+        h1 = workspace(tag + ("ws_h1ring",), (2, N, Hd), dt, dev)
+        h2 = workspace(tag + ("ws_h2ring",), (2, N, Hd), dt, dev)
+    whp, O, hpart = None, 0, None
+    if head is not None:
+        whp, O = head
+        hpart = out["head_partial"] = workspace(tag + ("ws_hpart", O), (1, Tn, N, O), torch.float32, dev)
+    _timed(("lstm2_fwd_ws", int(train), N, Tn, nch), lambda: H.call(
+        "nppc_lstm2_fwd_ws", int(train), x_tm, packed.wsp1, packed.wsp2, packed.bias1, packed.bias2, h1, h2, out.get("g1"),
+        out.get("g2"), out.get("c1"), out.get("c2"), cst, flags, whp, hpart, O, N, Tn, ncl, nch, H.stream()))
     return out
 
 

@@ -211,6 +211,20 @@ int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, cons
                              float* hpart, int O, void* stream);
 int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
                           void* stream);
+/* Weight-STATIONARY forward of the same LSTM (sequence_model.py:113-123; bf16, H = 384, I <= 64, N % 32 == 0): clusters of
+ * 12 CUs keep all weights in registers for the whole launch and exchange the hidden state instead (csrc/lstm_ws.hip).
+ * nppc_lstm2_ws_plan: clusters == 0 -> not applicable.  wp1 / wp2: nppc_lstm2_ws_pack of the fp32 weights.
+ * train = 0: h1 / h2 are [2][N][H] exchange rings and g / c may be null; train = 1: the saved state of nppc_lstm2_fwd
+ * (h1 / h2 [Tn][N][H] double as the exchange medium).  cst: clusters * nch_max * 2048 floats of scratch; flags: clusters *
+ * nch_max * 16 + 4 u32, the last 4 behind the epochs hold the sticky time-out counter (never cleared here).
+ * whp != null: hpart [Tn][N][O] fp32 = h2[t][n][:] . whp[o][:] (finish with nppc_sb_head_finalize, G = 1). */
+int nppc_lstm2_ws_plan(int prec, long N, int H, int I, int n_cu, int* clusters, int* nch_max);
+int nppc_lstm2_ws_packed_elems(long* n1, long* n2);
+int nppc_lstm2_ws_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wp1, void* wp2,
+                       void* stream);
+int nppc_lstm2_fwd_ws(int train, const void* x, const void* wp1, const void* wp2, const float* bias1, const float* bias2, void* h1,
+                      void* h2, void* g1, void* g2, void* c1, void* c2, float* cst, unsigned* flags, const void* whp, float* hpart,
+                      int O, long N, int Tn, int clusters, int nch_max, void* stream);
 /* cooperative backward (bf16, H = 384): CU pairs share 32 sequences, each owns half the hidden units / output columns */
 int nppc_lstm2_coop_bwd_packed_elems(long* n);
 int nppc_lstm2_coop_bwd_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,

@@ -232,7 +232,7 @@ def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
     fused = lstm2_forward(xt, pk, False, force, head=(wh, O))
     assert "head_partial" in fused and "h2" not in fused and ops_lstm.coop_timeouts() == 0
     got = torch.full_like(want, float("nan"))
-    H.call("nppc_sb_head_finalize", fused["head_partial"], 2, bias, got, N, Tn, la, O, Fo, s)
+    H.call("nppc_sb_head_finalize", fused["head_partial"], fused["head_partial"].shape[0], bias, got, N, Tn, la, O, Fo, s)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(got).all())
     assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))      # same bf16 operands, fp32 sums
@@ -250,7 +250,7 @@ def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
         H.call("nppc_sb_head", 0, ref_state["h2"], wh2, b2, want2, N, Tn, la, Hd, O2, Fo, s)
         tr = lstm2_forward(xt, pk, True, force, head=(wh2, O2))
         got2 = torch.full_like(want2, float("nan"))
-        H.call("nppc_sb_head_finalize", tr["head_partial"], 2, b2, got2, N, Tn, la, O2, Fo, s)
+        H.call("nppc_sb_head_finalize", tr["head_partial"], tr["head_partial"].shape[0], b2, got2, N, Tn, la, O2, Fo, s)
         torch.cuda.synchronize()
         assert ops_lstm.coop_timeouts() == 0
         assert float((got2 - want2).abs().max()) < 2e-5 * max(1.0, float(want2.abs().max()))
@@ -354,7 +354,7 @@ def test_production_restorer_forward_full_width_against_fp32_kernel():
     fused = lstm2_forward(x16, pk16, False, None, head=(wh32.to(torch.bfloat16), O))
     assert "head_partial" in fused
     got = torch.full_like(want, float("nan"))
-    H.call("nppc_sb_head_finalize", fused["head_partial"], 2, bias, got, N, Tn, la, O, Fo, s)
+    H.call("nppc_sb_head_finalize", fused["head_partial"], fused["head_partial"].shape[0], bias, got, N, Tn, la, O, Fo, s)
     torch.cuda.synchronize()
     assert ops_lstm.coop_timeouts() == 0
     assert bool(torch.isfinite(got).all())
@@ -427,3 +427,48 @@ def test_handoff_timeout_counter_is_sticky():
     with pytest.raises(RuntimeError, match="hand-off time-out"):
         ops_lstm.check_coop_timeouts("test")
     assert ops_lstm.coop_timeouts() == 0
+
+
+@pytest.mark.parametrize("N,Tn,train,O", [(128, 9, False, 2), (256, 7, True, 10), (416, 6, False, 4), (416, 5, True, 16),
+                                          (1024, 5, True, 10), (2688, 4, False, 2)])
+def test_weight_stationary_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train, O):
+    """The 12-CU weight-stationary cluster kernel (csrc/lstm_ws.hip: weights in registers, one fused hand-off per time step,
+    chunks of 32 sequences walked round robin; 1, 2, 3 (ragged: 4/5/4 chunks), 8 and 21 clusters) against the single-workgroup
+    streaming kernel of the same precision and the oracle; head fused; no bounded spin may time out."""
+    from nppc_audio import _hip as H
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import PackedLSTM, lstm2_forward, ws_plan
+    I, Hd, Fo, la = 34, 384, N // 2, 1
+    P = _weights(I, Hd, 7)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in (
+        "weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")])
+    assert ws_plan(N, pk) is not None
+    g = torch.Generator().manual_seed(N + Tn)
+    x = torch.randn(N, Tn, I, generator=g)
+    xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
+    xt[:, :, :I] = x.permute(1, 0, 2).to(dev)
+    wh = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev)
+    wh[:O] = (torch.randn(O, Hd, generator=g) * 0.1).to(dev)
+    bias = torch.randn(O, generator=g).to(dev)
+    s = H.stream()
+    ops_lstm.clear_coop_timeouts()
+    single = {k: v.clone() for k, v in lstm2_forward(xt, pk, train, 1).items()}
+    want = torch.empty(N // Fo, O, Fo, Tn - la, dtype=torch.float32, device=dev)
+    H.call("nppc_sb_head", 0, single["h2"], wh, bias, want, N, Tn, la, Hd, O, Fo, s)
+    ws = lstm2_forward(xt, pk, train, "ws", head=(wh, O))
+    assert "head_partial" in ws and ws["head_partial"].shape[0] == 1
+    got = torch.full_like(want, float("nan"))
+    H.call("nppc_sb_head_finalize", ws["head_partial"], 1, bias, got, N, Tn, la, O, Fo, s)
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    assert bool(torch.isfinite(got).all())
+    assert float((got - want).abs().max()) < 2e-2 * max(1.0, float(want.abs().max()))
+    if train:
+        ref = R.lstm2(x, P, "sb_model.sequence_model")
+        assert (ws["h2"].float().cpu().permute(1, 0, 2) - ref).abs().max().item() < 3e-2
+        for k in ("h1", "h2", "c1", "c2", "g1", "g2"):
+            d = (ws[k].float() - single[k].float()).abs().max().item()
+            assert d < 2e-2, (k, d)      # same bf16 arithmetic, different accumulation order
+        assert float(ws["h1_rows"][Tn * N:].abs().max()) == 0 and float(ws["h2_rows"][Tn * N:].abs().max()) == 0
