@@ -26,6 +26,7 @@
 // Results never depend on placement or dispatch order; what must hold is co-residency of a cluster's 12 workgroups, which
 // the launcher guarantees (one workgroup per CU: > 80 KB of LDS, grid <= CU count, occupancy checked).  Every spin is
 // bounded; a time-out adds 1 to the sticky counter behind the flag words (same contract as lstm_coop.hip).
+#include <stdlib.h>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -43,10 +44,17 @@ constexpr int WS_ROWB = (WS_KX + 2 * WS_H) * 2 + 16;     // 1680 bytes per tile 
 constexpr int WS_TILEB = WS_MC * WS_ROWB;                // 53760
 constexpr int WS_OFF_BIAS = 2 * WS_TILEB;                // [2 layers][32 units][4 gates (i,g,f,o)] fp32
 constexpr int WS_OFF_WH = WS_OFF_BIAS + 2 * WS_UC * 16;  // head weights as 16x16x32 A fragments [12 kk][64 lanes][8] bf16
-constexpr int WS_SMEM = WS_OFF_WH + 12 * 64 * 16;
+constexpr int WS_NKL = 4;                                // layer-2 k-steps whose A fragments stay in LDS (register budget)
+constexpr int WS_OFF_W2L = WS_OFF_WH + 12 * 64 * 16;     // [4 ug][WS_NKL][64 lanes][8] bf16
+constexpr int WS_OFF_CNT = WS_OFF_W2L + 4 * WS_NKL * 1024; // readers-done counter of the output staging (training), 16 bytes
+constexpr int WS_OFF_STG = WS_OFF_CNT + 16;              // output staging [2 layers][32 seq][STROW] (inference: x 2 item parities)
+constexpr int WS_STROW_INF = 64 + 16;                    // inference: the CU's 32 units of h (64 B) + pad
+constexpr int WS_STROW_TRN = 256 + 64 + 64 + 16;         // training: gates (256 B) | c (64 B) | h (64 B) + pad
+constexpr int ws_smem(bool train) { return WS_OFF_STG + (train ? 2 * WS_MC * WS_STROW_TRN : 2 * 2 * WS_MC * WS_STROW_INF); }
+constexpr int WS_PF = 6;                                 // B fragments (LDS reads) in flight per wave
 constexpr int WS_HB = WS_H * 2;                          // bytes of one h row
 constexpr unsigned WS_SPIN_LIMIT = 1u << 22;
-static_assert(WS_SMEM > 80 * 1024 && WS_SMEM <= 160 * 1024, "one workgroup per CU");
+static_assert(ws_smem(false) > 80 * 1024 && ws_smem(true) <= 160 * 1024, "one workgroup per CU");
 
 struct WsArgs {
   const void* x;        // [Tn][N][64] bf16
@@ -62,6 +70,7 @@ struct WsArgs {
   const void* whp;      // head weights [16][H] bf16 row-major (rows >= O zero); nullptr: no head
   float* hpart;         // [Tn][N][O] fp32 head sums (bias and re-layout: nppc_sb_head_finalize with G = 1)
   long N; int Tn; int O; int clusters; int nch_max; int nchunks;
+  int prio;             // 1: the layer-2 waves (the longer GEMM) run at raised priority
 };
 
 // workgroup -> (cluster, cu).  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the blocks that share one); with the
@@ -90,6 +99,18 @@ __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f
 
 // LDS-only workgroup barrier: does not drain the wave's global stores (the publish stores of THIS item stay in flight)
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// diagnostic phase timers (tools/diag/stamp_ws.py builds with -DWS_STAMP): wave 0 (layer 1) and wave 4 (layer 2) of the
+// workgroup (cluster 0, cu 0) accumulate cycles per phase and leave them behind the time-out words of the flag block
+#ifdef WS_STAMP
+#define WST_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WST(i) if (st_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long nw = __builtin_readcyclecounter(); st_acc[i] += nw - st_last; st_last = nw; __builtin_amdgcn_sched_barrier(0); }
+#define WST_FINI(base) if (st_on && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) ((unsigned long long*)(a.flags + (size_t)a.clusters * a.nch_max * 16 + 4))[(base) + i_] = st_acc[i_]; }
+#else
+#define WST_INIT
+#define WST(i)
+#define WST_FINI(base)
+#endif
 
 struct WsItem {
   int s, c;             // fused step, local chunk
@@ -129,12 +150,68 @@ __device__ __forceinline__ void ws_cell(const f32x16& acc, f32x4& c, unsigned (&
   }
 }
 
-// the 8 units of a sequence sit in two lanes (l: units 0-3, l + 32: units 4-7): bring both halves into the lower lane
-__device__ __forceinline__ u32x4 ws_join(const unsigned (&hpk)[2]) {
-  const auto r0 = __builtin_amdgcn_permlane32_swap(hpk[0], hpk[0], false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap(hpk[1], hpk[1], false, false);
-  return u32x4{r0[0], r1[0], r0[1], r1[1]};
+// Outputs of an item leave through LDS: behind its cell update every wave drops its 8 units x 32 sequences into the layer's
+// staging rows (ws_stage_out), the item's barrier follows, and at the top of the NEXT iteration wave w stores rows [4 w, 4 w + 4)
+// of both layers as whole 64 / 256-byte row segments (ws_flush).  Stored straight from the accumulator lanes, every store
+// instruction touched 32 different 128-byte lines with 16-32 bytes each, and the vector-memory path is bound by lines, not
+// bytes (1.8k of 6.6k cycles per item in training).  h leaves write-through (sc1: the hand-off payload), gates and c
+// non-temporal.  The flag of the item still rises behind the NEXT barrier, as before: the stores are now the oldest of that
+// iteration instead of the youngest of the previous one.
+// Inference stages into two buffers by item parity (the barrier between an item's flush and the second-next item's writes
+// orders them); training has room for one: its writers wait for the readers-done counter (8 x items flushed), which the
+// flushing waves bump behind their reads -- LDS operations execute in issue order -- and which practically never waits.
+template <bool TRAIN>
+__device__ __forceinline__ unsigned char* ws_stg(unsigned char* smem, int layer, int par) {
+  return smem + WS_OFF_STG + (TRAIN ? layer * WS_MC * WS_STROW_TRN : (par * 2 + layer) * WS_MC * WS_STROW_INF);
 }
+template <bool TRAIN>
+__device__ __forceinline__ void ws_stage_out(unsigned char* smem, int layer, int ug, int lane, int i, const unsigned (&hpk)[2],
+                                             const u32x4 (&gpk)[2], const unsigned (&cpk)[2]) {
+  constexpr int STROW = TRAIN ? WS_STROW_TRN : WS_STROW_INF;
+  constexpr int HOFF = TRAIN ? 320 : 0;
+  asm volatile("" : "+v"(lane));        // re-derive the addresses below per item: hoisted, they would live in VGPRs across the GEMMs
+  const int seq = lane & 31, hh = lane >> 5;
+  if (TRAIN) {
+    volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + WS_OFF_CNT);
+    for (unsigned spins = 0; *cnt < 8u * (unsigned)i && spins < (1u << 20); ++spins) {}
+  }
+  unsigned char* wrow = ws_stg<TRAIN>(smem, layer, i & 1) + seq * STROW;
+  if (TRAIN) {
+    *reinterpret_cast<u32x4*>(wrow + ug * 64 + hh * 32) = gpk[0];
+    *reinterpret_cast<u32x4*>(wrow + ug * 64 + hh * 32 + 16) = gpk[1];
+    *reinterpret_cast<u32x2*>(wrow + 256 + ug * 16 + hh * 8) = u32x2{cpk[0], cpk[1]};
+  }
+  *reinterpret_cast<u32x2*>(wrow + HOFF + ug * 16 + hh * 8) = u32x2{hpk[0], hpk[1]};
+}
+// stores of wave `wave` for the item staged in iteration ip: 2 (h) + TRAIN 4 (gates, c) store instructions, every path
+template <bool TRAIN>
+__device__ __forceinline__ void ws_flush(unsigned char* smem, int wave, int lane, int ip, int row0, int cu, __amdgpu_buffer_rsrc_t h1r,
+                                         __amdgpu_buffer_rsrc_t h2r, __amdgpu_buffer_rsrc_t g1r, __amdgpu_buffer_rsrc_t g2r,
+                                         __amdgpu_buffer_rsrc_t c1r, __amdgpu_buffer_rsrc_t c2r) {
+  constexpr int STROW = TRAIN ? WS_STROW_TRN : WS_STROW_INF;
+  constexpr int HOFF = TRAIN ? 320 : 0;
+  asm volatile("" : "+v"(lane));        // (see ws_stage_out)
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+    const unsigned char* stg = ws_stg<TRAIN>(smem, layer, ip & 1);
+    if (TRAIN) {
+      const int r = 4 * wave + (lane >> 4), col = lane & 15;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + col * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(v, layer ? g2r : g1r, (row0 + r) * (WS_H * 8) + cu * 256 + col * 16, 0, 2);
+    }
+    const int r = 4 * wave + ((lane & 15) >> 2), col = lane & 3;
+    const int goff = lane < 16 ? (row0 + r) * WS_HB + cu * 64 + col * 16 : 0x7ffffff0;   // lanes 16-63: out of range, dropped
+    if (TRAIN) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + 256 + col * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(v, layer ? c2r : c1r, goff, 0, 2);
+    }
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + HOFF + col * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, layer ? h2r : h1r, goff, 0, 16);
+  }
+  if (TRAIN && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(smem + WS_OFF_CNT), 1u);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const lds_u8* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 template <bool TRAIN>
 __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
@@ -161,6 +238,7 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       const int tg = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 3));
       bl[e] = (l ? a.bias2 : a.bias1)[tg * WS_H + cu * WS_UC + u];
     }
+    if (tid < 4) reinterpret_cast<unsigned*>(smem + WS_OFF_CNT)[tid] = 0u;
     if (a.whp) {
       const bf16_t* wh = reinterpret_cast<const bf16_t*>(a.whp);
       for (int e = tid; e < 12 * 64; e += WS_NT) {
@@ -175,7 +253,10 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
   const lds_u8* ltile = reinterpret_cast<const lds_u8*>(smem);
   // B fragment (activations) of this lane: row seq, k = 8 hh + j of each 16-wide k-step
   const int boff = seq * WS_ROWB + hh * 16 + (layer ? WS_KX * 2 : 0);
-  float* cst = a.cst + (((size_t)cluster * WS_G + cu) * a.nch_max * 2 + layer) * 4 * 256 + ug * 256 + lane * 4;   // + c * 2*4*256
+  // fp32 cell state of (chunk, layer, unit group): 16 bytes per lane, private to this wave (plain accesses, L2-resident);
+  // addressed through a descriptor: scalar chunk offset + the lane offset, no 64-bit pointer per lane
+  const __amdgpu_buffer_rsrc_t cstr = __builtin_amdgcn_make_buffer_rsrc(
+      a.cst + (((size_t)cluster * WS_G + cu) * a.nch_max * 2 + layer) * 4 * 256 + ug * 256, 0, (unsigned)a.nch_max * 2 * 4 * 256 * 4, 0x00020000);
 
   auto mk_item = [&](int s_, int c_) {
     WsItem it;
@@ -186,9 +267,25 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
   };
   auto next_item = [&](const WsItem& it) { return it.c + 1 < nch ? mk_item(it.s, it.c + 1) : mk_item(it.s + 1, 0); };
   auto slot = [&](int t) -> long { return TRAIN ? t : (t & 1); };
-  // fp32 cell state of (chunk, layer, unit group): 16 bytes per lane, private to this wave (plain, L2-resident)
-  auto cst_of = [&](const WsItem& it) { return cst + (size_t)it.c * 2 * 4 * 256; };
+  auto cst_load = [&](const WsItem& it) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cstr, lane * 16, it.c * 2 * 4 * 256 * 4, 0));
+  };
+  auto cst_store = [&](const WsItem& it, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), cstr, lane * 16, it.c * 2 * 4 * 256 * 4, 0);
+  };
 
+#ifdef WS_STAMP
+  const bool st_on = cluster == 0 && cu == 0 && ug == 0;
+#endif
+  // stores of the item staged in iteration ip (fused step sp, chunk row0p): h1 of time sp, h2 / layer-2 state of time sp - 1
+  auto flush = [&](int ip, const WsItem& pit) {
+    const int sp = pit.s;
+    const bool a1 = sp < Tn, a2 = sp >= 1 && sp <= Tn;
+    ws_flush<TRAIN>(smem, wave, lane, ip, (int)pit.row0, cu, ws_rsrc(a.h1, slot(sp), N, WS_HB, a1),
+                    ws_rsrc(a.h2, slot(sp - 1), N, WS_HB, a2), ws_rsrc(a.g1, sp, N, WS_H * 8, a1 && TRAIN),
+                    ws_rsrc(a.g2, sp - 1, N, WS_H * 8, a2 && TRAIN), ws_rsrc(a.c1, sp, N, WS_HB, a1 && TRAIN),
+                    ws_rsrc(a.c2, sp - 1, N, WS_HB, a2 && TRAIN));
+  };
   if (layer == 0) {
     // =============================== layer-1 waves: staging + layer 1 + head ===============================
     bf16x8 w[WS_NK1];
@@ -234,11 +331,14 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
     stage_write(0);
     f32x4 cc = {0.f, 0.f, 0.f, 0.f};                               // cell state of the current item (s = 0: zero)
     __syncthreads();
+    WST_INIT
 
 #pragma unroll 1
     for (int i = 0; i < nitems; ++i) {
       const int buf = i & 1;
       const bool more = i + 1 < nitems;
+      if (i >= 1) flush(i - 1, itp);                                // the previous item's outputs: oldest stores of this iteration
+      __builtin_amdgcn_sched_barrier(0);
       // ---- head of time s - 2 from the full h2_{s-2} in the tile: waves 2, 3 of the chunk's designated CU.  FIRST in the
       // iteration: its (conditional) stores must be older than the gather below, so that the waits for the gather can be
       // counted ones that leave this item's unconditional stores in flight
@@ -256,16 +356,15 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           if (4 * q + j < a.O) __builtin_nontemporal_store(hacc[j], hp + 4 * q + j);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // next item's cell state (older than everything below: waiting for it never waits for this item's stores), then the
-      // next item's gather
-      f32x4 ccn = *reinterpret_cast<const f32x4*>(cst_of(itn));
+      // next item's cell state (older than everything below: waiting for it never waits for this item's stores)
+      f32x4 ccn = cst_load(itn);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) stage_issue(itn);
-      __builtin_amdgcn_sched_barrier(0);
+      WST(0)
       {
         // ---- layer 1 of time s: gates = W1 . [x_s | h1_{s-1}]^T + b.  Executed for EVERY item (the steps behind the last
-        // time step compute on zeros and store through an empty descriptor): no store sits in a conditional path
-        const bool act = it.s < Tn;
+        // time step compute on zeros and store through an empty descriptor): no store sits in a conditional path.
+        // The gather of the NEXT item is issued between the MFMAs, one 1 KB load per two k-steps: issued in one burst the
+        // 56 loads of the four staging waves fill the CU's vector-memory queue and every wave blocks at the issue
         f32x16 acc;
         {
           const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (ug * 8 + 4 * hh) * 16;
@@ -276,57 +375,87 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           }
         }
         const lds_u8* bp = ltile + buf * WS_TILEB + boff;
+        const int th = (ug >> 1) ? itn.s - 2 : itn.s - 1;            // time of the h rows this wave gathers
+        const __amdgpu_buffer_rsrc_t ghr = ws_rsrc((ug >> 1) ? a.h2 : a.h1, slot(th), N, WS_HB, more && th >= 0 && th < Tn);
+        const __amdgpu_buffer_rsrc_t gxr = ws_rsrc(a.x, itn.s, N, WS_KX * 2, more && itn.s < Tn);
+        const int gso = (int)(itn.row0 + 16 * (ug & 1)) * WS_HB;
+        bf16x8 b[WS_PF];
 #pragma unroll
-        for (int ks = 0; ks < WS_NK1; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], *reinterpret_cast<const bf16x8*>(bp + ks * 32), acc, 0, 0, 0);
+        for (int d = 0; d < WS_PF; ++d) b[d] = lds_frag(bp + d * 32);
+#pragma unroll
+        for (int ks = 0; ks < WS_NK1; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b[ks % WS_PF], acc, 0, 0, 0);
+          if (ks + WS_PF < WS_NK1) b[ks % WS_PF] = lds_frag(bp + (ks + WS_PF) * 32);
+          if ((ks & 1) && (ks >> 1) < 12) {
+            const int j = ks >> 1;
+            st[j] = __builtin_amdgcn_raw_buffer_load_b128(ghr, sv[j % 3], gso + (j / 3) * 4 * WS_HB, 16);
+          }
+          if (ks == 25) st[12] = __builtin_amdgcn_raw_buffer_load_b128(gxr, lane * 16, (int)(itn.row0 + 8 * ug) * WS_KX * 2, 0);
+        }
+        // pin the software pipeline (left alone, the scheduler sinks every LDS read to just in front of its MFMA and the
+        // wave pays the LDS latency once per two MFMAs): bias + first WS_PF reads, then one read (and every other step one
+        // gather load) behind each MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + WS_PF, 0);
+#pragma unroll
+        for (int ks = 0; ks < WS_NK1; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (ks & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        WST(1)
         unsigned hpk[2], cpk[2];
         u32x4 gpk[2];
         if (it.s == 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
         ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
-        *reinterpret_cast<f32x4*>(cst_of(it)) = cc;
-        const u32x4 hj = ws_join(hpk);
-        const int roff = (int)(it.row0 + seq);
-        if (TRAIN) {
-          const __amdgpu_buffer_rsrc_t gr = ws_rsrc(a.g1, it.s, N, WS_H * 8, act);
-          const __amdgpu_buffer_rsrc_t cr = ws_rsrc(a.c1, it.s, N, WS_HB, act);
-          __builtin_amdgcn_raw_buffer_store_b128(gpk[0], gr, roff * (WS_H * 8) + unit0 * 8, 0, 2);
-          __builtin_amdgcn_raw_buffer_store_b128(gpk[1], gr, roff * (WS_H * 8) + unit0 * 8 + 16, 0, 2);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{cpk[0], cpk[1]}, cr, roff * WS_HB + unit0 * 2, 0, 2);
-        }
-        const __amdgpu_buffer_rsrc_t hr = ws_rsrc(a.h1, slot(it.s), N, WS_HB, act);
-        // lanes 32-63 hold copies: their offset is out of range, the store is dropped (no branch around the store)
-        __builtin_amdgcn_raw_buffer_store_b128(hj, hr, lane < 32 ? roff * WS_HB + (cu * WS_UC + ug * 8) * 2 : 0x7ffffff0, 0, 16);
+        cst_store(it, cc);
+        ws_stage_out<TRAIN>(smem, 0, ug, lane, i, hpk, gpk, cpk);
       }
       __builtin_amdgcn_sched_barrier(0);
+      WST(2)
       // every store of item i - 1 is complete once this wait for the gather has passed: the gather was issued behind them and
       // a wave's vector-memory operations retire in order
-      if (more) stage_write(buf ^ 1);
-      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      stage_write(buf ^ 1);
       cc = ccn;                                                    // (the wait for ccn is older still)
+      WST(3)
       ws_barrier();
+      WST(4)
       if (tid == 0 && i >= 1)
         __hip_atomic_store(flags + itp.c * 16 + cu, (unsigned)(itp.s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       itp = it;
       it = itn;
       itn = next_item(itn);
     }
+    flush(nitems - 1, itp);                                         // (the last item's barrier has been passed)
+    WST_FINI(0)
   } else {
     // =============================== layer-2 waves (wave 4 also polls) ===============================
-    bf16x8 w[WS_NK2];
+    // waves 4-7 are the younger half of the workgroup and lose the issue arbitration against the layer-1 wave on their
+    // SIMD (MI355X_MICROARCH, two waves per SIMD, items 2 and 4) although theirs is the longer chain: static priority
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
+    constexpr int NKR = WS_NK2 - WS_NKL;                             // k-steps with register-resident weights: NKL .. 47
+    bf16x8 w[NKR];
     {
       const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.wp2) + ((size_t)(cu * 4 + ug) * WS_NK2) * 512 + lane * 8;
 #pragma unroll
-      for (int ks = 0; ks < WS_NK2; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
+      for (int ks = 0; ks < WS_NKL; ++ks)                            // the first k-steps' A fragments live in LDS
+        *reinterpret_cast<bf16x8*>(smem + WS_OFF_W2L + ((ug * WS_NKL + ks) * 64 + lane) * 16) =
+            *reinterpret_cast<const bf16x8*>(wp + ks * 512);
+#pragma unroll
+      for (int ks = WS_NKL; ks < WS_NK2; ++ks) w[ks - WS_NKL] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
+    const lds_u8* wl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_W2L + (ug * WS_NKL * 64 + lane) * 16;
     __syncthreads();
-    WsItem it = mk_item(0, 0), itn = next_item(it), it2 = next_item(itn);
-    f32x4 cc = {0.f, 0.f, 0.f, 0.f};
+    WsItem it = mk_item(0, 0), itn = next_item(it), it2 = next_item(itn), itp = it;
     __syncthreads();
+    WST_INIT
 #pragma unroll 1
     for (int i = 0; i < nitems; ++i) {
       const int buf = i & 1;
-      f32x4 ccn = *reinterpret_cast<const f32x4*>(cst_of(itn));
+      const int t = it.s - 1;
+      if (i >= 1) flush(i - 1, itp);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 cc = cst_load(it);
       // wave 4: the flags of item i + 2 (its gather starts right behind this iteration's barrier): requested here, looked
       // at behind the GEMM.  Every CU of the cluster must have published item (c, s - 1).
       const bool polls = ug == 0 && i + 2 < nitems && it2.s >= 1;
@@ -334,40 +463,51 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       if (polls && lane < WS_G) pv = __hip_atomic_load(flags + it2.c * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_sched_barrier(0);
       const bool active = it.s >= 1 && it.s <= Tn;
+      // ---- layer 2 of time s - 1: gates = W2 . [h1_{s-1} | h2_{s-2}]^T + b (every item: see layer 1)
+      f32x16 acc;
       {
-        // ---- layer 2 of time s - 1: gates = W2 . [h1_{s-1} | h2_{s-2}]^T + b (every item: see layer 1)
-        const int t = it.s - 1;
-        f32x16 acc;
-        {
-          const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (WS_UC + ug * 8 + 4 * hh) * 16;
+        const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (WS_UC + ug * 8 + 4 * hh) * 16;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
-            acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+        for (int m = 0; m < 4; ++m) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
+          acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+        }
+      }
+      {
+        // one ring of WS_PF LDS reads in flight feeds the MFMAs: operand stream W_0 B_0 .. W_{NKL-1} B_{NKL-1} B_NKL .. B_47
+        // (the first NKL k-steps take their A fragment from LDS as well: 176 + 16 + 24 registers at the peak)
+        const lds_u8* bp = ltile + buf * WS_TILEB + boff;
+        constexpr int E = WS_NK2 + WS_NKL;
+        bf16x8 r[WS_PF];
+        auto rd = [&](int e) {
+          if (e < 2 * WS_NKL) return (e & 1) ? lds_frag(bp + (e >> 1) * 32) : lds_frag(wl + (e >> 1) * 1024);
+          return lds_frag(bp + (e - WS_NKL) * 32);
+        };
+#pragma unroll
+        for (int e = 0; e < WS_PF; ++e) r[e] = rd(e);
+#pragma unroll
+        for (int ks = 0; ks < WS_NK2; ++ks) {
+          if (ks < WS_NKL) {
+            const int e = 2 * ks;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r[e % WS_PF], r[(e + 1) % WS_PF], acc, 0, 0, 0);
+            if (e + WS_PF < E) r[e % WS_PF] = rd(e + WS_PF);
+            if (e + 1 + WS_PF < E) r[(e + 1) % WS_PF] = rd(e + 1 + WS_PF);
+          } else {
+            const int e = WS_NKL + ks;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks - WS_NKL], r[e % WS_PF], acc, 0, 0, 0);
+            if (e + WS_PF < E) r[e % WS_PF] = rd(e + WS_PF);
           }
         }
-        const lds_u8* bp = ltile + buf * WS_TILEB + boff;
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + WS_PF, 0);   // (see layer 1)
 #pragma unroll
-        for (int ks = 0; ks < WS_NK2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], *reinterpret_cast<const bf16x8*>(bp + ks * 32), acc, 0, 0, 0);
-        unsigned hpk[2], cpk[2];
-        u32x4 gpk[2];
-        if (t <= 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
-        ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
-        *reinterpret_cast<f32x4*>(cst_of(it)) = cc;
-        const u32x4 hj = ws_join(hpk);
-        const int roff = (int)(it.row0 + seq);
-        if (TRAIN) {
-          const __amdgpu_buffer_rsrc_t gr = ws_rsrc(a.g2, t, N, WS_H * 8, active);
-          const __amdgpu_buffer_rsrc_t cr = ws_rsrc(a.c2, t, N, WS_HB, active);
-          __builtin_amdgcn_raw_buffer_store_b128(gpk[0], gr, roff * (WS_H * 8) + unit0 * 8, 0, 2);
-          __builtin_amdgcn_raw_buffer_store_b128(gpk[1], gr, roff * (WS_H * 8) + unit0 * 8 + 16, 0, 2);
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{cpk[0], cpk[1]}, cr, roff * WS_HB + unit0 * 2, 0, 2);
+        for (int ks = 0; ks < WS_NK2; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (ks < WS_NKL) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        const __amdgpu_buffer_rsrc_t hr = ws_rsrc(a.h2, slot(t), N, WS_HB, active);
-        __builtin_amdgcn_raw_buffer_store_b128(hj, hr, lane < 32 ? roff * WS_HB + (cu * WS_UC + ug * 8) * 2 : 0x7ffffff0, 0, 16);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      WST(1)
+      // the poll BEFORE this item's stores: the wait for the flag words then never covers a write-through store
       if (polls) {
         unsigned spins = 0;
         while (__builtin_amdgcn_ballot_w64(pv < (unsigned)it2.s) != 0) {
@@ -381,16 +521,30 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only: the payload loads are sc1
       }
       __builtin_amdgcn_sched_barrier(0);
-      // every store of item i - 1 must be complete before this barrier (the flag of item i - 1 is raised behind it): leave
-      // only THIS item's stores in flight
-      if (TRAIN) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      cc = ccn;
+      WST(2)
+      {
+        unsigned hpk[2], cpk[2];
+        u32x4 gpk[2];
+        if (t <= 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
+        ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
+        cst_store(it, cc);
+        ws_stage_out<TRAIN>(smem, 1, ug, lane, i, hpk, gpk, cpk);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the stores of item i - 1 (flushed at the top of this iteration) must be complete before this barrier, the flag of
+      // item i - 1 is raised behind it: leave only the cell-state store of THIS item in flight
+      WST(3)
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      WST(4)
       ws_barrier();
+      WST(5)
+      itp = it;
       it = itn;
       itn = it2;
       it2 = next_item(it2);
     }
+    flush(nitems - 1, itp);
+    WST_FINI(8)
   }
 }
 
@@ -420,7 +574,7 @@ __global__ void lstm_ws_pack_kernel(const float* __restrict__ w_ih, const float*
   }
 }
 
-static int ws_fits(const void* kernel, int& per_cu_cache, int& n_cu) {
+static int ws_fits(const void* kernel, int smem, int& per_cu_cache, int& n_cu) {
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
@@ -429,7 +583,7 @@ static int ws_fits(const void* kernel, int& per_cu_cache, int& n_cu) {
   }
   n_cu = ncu;
   if (per_cu_cache < 0 &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cache, kernel, WS_NT, WS_SMEM) != hipSuccess)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cache, kernel, WS_NT, smem) != hipSuccess)
     return NPPC_ELAUNCH;
   return per_cu_cache >= 1 ? NPPC_OK : NPPC_EUNSUPPORTED;
 }
@@ -484,20 +638,22 @@ int nppc_lstm2_fwd_ws(int train, const void* x, const void* wp1, const void* wp2
   if (N % WS_MC) return NPPC_EUNSUPPORTED;
   const long nchunks = N / WS_MC;
   if ((long)clusters * nch_max < nchunks || nchunks / clusters < 4 || N * (long)WS_H * 8 >= (1l << 31)) return NPPC_EBADARG;
-  WsArgs a{x, wp1, wp2, bias1, bias2, h1, h2, g1, g2, c1, c2, cst, flags, whp, hpart, N, Tn, O, clusters, nch_max, (int)nchunks};
+  static const int prio = [] { const char* e = getenv("NPPC_WS_PRIO"); return e ? atoi(e) : 0; }();
+  WsArgs a{x, wp1, wp2, bias1, bias2, h1, h2, g1, g2, c1, c2, cst, flags, whp, hpart, N, Tn, O, clusters, nch_max, (int)nchunks, prio};
   hipStream_t s = (hipStream_t)stream;
   const void* k = train ? reinterpret_cast<const void*>(lstm2_ws_fwd_kernel<true>)
                         : reinterpret_cast<const void*>(lstm2_ws_fwd_kernel<false>);
-  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM) != hipSuccess) return NPPC_ELAUNCH;
+  const int smem = ws_smem(train != 0);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return NPPC_ELAUNCH;
   static int per_cu[2] = {-1, -1};
   int n_cu = 0;
-  const int fits = ws_fits(k, per_cu[train ? 1 : 0], n_cu);
+  const int fits = ws_fits(k, smem, per_cu[train ? 1 : 0], n_cu);
   if (fits != NPPC_OK) return fits;
   if (clusters * WS_G > n_cu) return NPPC_EUNSUPPORTED;         // every workgroup of a cluster must be resident
   if (hipMemsetAsync(flags, 0, (size_t)clusters * nch_max * 16 * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   const int grid = n_cu == 256 ? 256 : clusters * WS_G;
-  if (train) hipLaunchKernelGGL(lstm2_ws_fwd_kernel<true>, dim3(grid), dim3(WS_NT), WS_SMEM, s, a);
-  else hipLaunchKernelGGL(lstm2_ws_fwd_kernel<false>, dim3(grid), dim3(WS_NT), WS_SMEM, s, a);
+  if (train) hipLaunchKernelGGL(lstm2_ws_fwd_kernel<true>, dim3(grid), dim3(WS_NT), smem, s, a);
+  else hipLaunchKernelGGL(lstm2_ws_fwd_kernel<false>, dim3(grid), dim3(WS_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

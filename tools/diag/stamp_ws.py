@@ -1,0 +1,51 @@
+"""Phase timers of the weight-stationary forward (built with -DWS_STAMP into tools/diag/libnppc_stampws.so).
+  python tools/diag/stamp_ws.py --build   (CPU)      python tools/diag/stamp_ws.py   (GPU box)"""
+import sys, os, subprocess, glob
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(root, "generative-audio_amd"))
+so = os.path.join(root, "tools", "diag", "libnppc_stampws.so")
+if "--build" in sys.argv:
+    csrc = os.path.join(root, "generative-audio_amd", "csrc")
+    objs = [os.path.join(root, "generative-audio_amd", "build", os.path.basename(f)[:-4] + ".o") for f in sorted(glob.glob(csrc + "/*.hip"))
+            if not f.endswith("lstm_ws.hip")]
+    o = "/tmp/lstm_ws_stamp.o"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DWS_STAMP", "-I" + os.path.join(root, "include"),
+                           "-I" + csrc, "-Wno-unused-value", "-c", os.path.join(csrc, "lstm_ws.hip"), "-o", o])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, o] + objs)
+    sys.exit(0)
+import torch
+from nppc_audio import _hip as H
+H.LIB_PATH = so
+from nppc_audio import ops_lstm
+from nppc_audio.ops_lstm import PackedLSTM, lstm2_forward
+dev = torch.device("cuda")
+I, Hd, Tn = 34, 384, 253
+torch.manual_seed(0)
+ws = [torch.randn(4*Hd, I)*.05, torch.randn(4*Hd, Hd)*.05, torch.zeros(4*Hd), torch.zeros(4*Hd), torch.randn(4*Hd, Hd)*.05, torch.randn(4*Hd, Hd)*.05, torch.zeros(4*Hd), torch.zeros(4*Hd)]
+ws = [w.to(dev) for w in ws]
+pk = PackedLSTM(I, Hd, 0, dev).pack(*ws)
+orig = ops_lstm.workspace
+def ws2(key, shape, dtype, device, zero=False):
+    if key[-1] == "coop_flags":
+        shape = (shape[0] + 64,)
+    return orig(key, shape, dtype, device, zero)
+ops_lstm.workspace = ws2
+n1 = ["flush prev + head + cc prefetch", "bias + GEMM (28 MFMA) + gather issue", "pointwise + stage-out", "wait gather + LDS write", "barrier", "-", "-", "-"]
+n2 = ["-", "flush prev + bias + GEMM (48 MFMA)", "poll check", "pointwise + stage-out", "store drain (vmcnt)", "barrier", "-", "-"]
+for N, train, O in ((8224, False, 2), (4096, True, 10), (4096, False, 10)):
+    x = torch.randn(Tn, N, pk.kx, device=dev).to(torch.bfloat16); x[:, :, I:] = 0
+    wh = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev); wh[:O] = (torch.randn(O, Hd) * 0.1).to(dev)
+    for _ in range(2):
+        lstm2_forward(x, pk, train, "ws", head=(wh, O))
+    torch.cuda.synchronize()
+    fl = [t for k, t in ops_lstm._WS.items() if k[0][-1] == "coop_flags"][-1]
+    ncl, nch = ops_lstm.ws_plan(N, pk)
+    base = ncl * nch * 16 + 4
+    dbg = fl[base: base + 32].view(torch.int64).cpu().tolist()
+    nitems = ((N // 32 + ncl - 1) // ncl) * (Tn + 2)
+    for nm, d, names in (("layer-1 wave 0", dbg[:8], n1), ("layer-2 wave 4", dbg[8:16], n2)):
+        tot = sum(d)
+        print(f"ws fwd N={N} train={train} {nm}: cycles/item {tot/nitems:.0f}  ({nitems} items, {tot/Tn:.0f} cycles/step)")
+        for nme, v in zip(names, d):
+            if nme != "-":
+                print(f"   {nme:40s} {v/nitems:9.1f}  {100*v/max(tot,1):5.1f}%")
