@@ -98,7 +98,11 @@ __device__ __forceinline__ bool ws_ids(int clusters, int& cluster, int& cu) {
 __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 
 // LDS-only workgroup barrier: does not drain the wave's global stores (the publish stores of THIS item stay in flight)
+#ifdef WS_DIAG_NOBARRIER
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // diagnostic: waves run free
+#else
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // diagnostic phase timers (tools/diag/stamp_ws.py builds with -DWS_STAMP): wave 0 (layer 1) and wave 4 (layer 2) of the
 // workgroup (cluster 0, cu 0) accumulate cycles per phase and leave them behind the time-out words of the flag block
@@ -114,7 +118,7 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 struct WsItem {
   int s, c;             // fused step, local chunk
-  long row0;            // first sequence of the chunk
+  int row0;             // first sequence of the chunk
 };
 
 // per-time-slot buffer descriptor: base + slot * N * row_bytes, N * row_bytes records (rows >= N and invalid times: range
@@ -128,6 +132,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base, long
 template <bool TRAIN>
 __device__ __forceinline__ void ws_cell(const f32x16& acc, f32x4& c, unsigned (&hpk)[2], u32x4 (&gpk)[2], unsigned (&cpk)[2]) {
   float hv[4];
+#ifdef WS_DIAG_NOCELL
+  // diagnostic build (timing only, results are garbage): no transcendentals, a handful of VALU instructions
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    c[m] = acc[4 * m] + acc[4 * m + 1] * c[m];
+    hv[m] = acc[4 * m + 2] + acc[4 * m + 3];
+    if (TRAIN) { gpk[m >> 1][2 * (m & 1)] = pack2(acc[4 * m], acc[4 * m + 1]); gpk[m >> 1][2 * (m & 1) + 1] = pack2(acc[4 * m + 2], acc[4 * m + 3]); }
+  }
+  hpk[0] = pack2(hv[0], hv[1]); hpk[1] = pack2(hv[2], hv[3]);
+  if (TRAIN) { cpk[0] = pack2(c[0], c[1]); cpk[1] = pack2(c[2], c[3]); }
+  return;
+#endif
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const float iv = sigmoid_f(acc[4 * m + 0]);
@@ -158,7 +174,7 @@ __device__ __forceinline__ void ws_cell(const f32x16& acc, f32x4& c, unsigned (&
 // non-temporal.  The flag of the item still rises behind the NEXT barrier, as before: the stores are now the oldest of that
 // iteration instead of the youngest of the previous one.
 // Inference stages into two buffers by item parity (the barrier between an item's flush and the second-next item's writes
-// orders them); training has room for one: its writers wait for the readers-done counter (8 x items flushed), which the
+// orders them); training has room for one: its writers wait for the readers-done counter (4 x generations flushed), which the
 // flushing waves bump behind their reads -- LDS operations execute in issue order -- and which practically never waits.
 template <bool TRAIN>
 __device__ __forceinline__ unsigned char* ws_stg(unsigned char* smem, int layer, int par) {
@@ -173,7 +189,7 @@ __device__ __forceinline__ void ws_stage_out(unsigned char* smem, int layer, int
   const int seq = lane & 31, hh = lane >> 5;
   if (TRAIN) {
     volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + WS_OFF_CNT);
-    for (unsigned spins = 0; *cnt < 8u * (unsigned)i && spins < (1u << 20); ++spins) {}
+    for (unsigned spins = 0; *cnt < 4u * (unsigned)(i + 1) && spins < (1u << 20); ++spins) {}   // generation i - 1 has been read
   }
   unsigned char* wrow = ws_stg<TRAIN>(smem, layer, i & 1) + seq * STROW;
   if (TRAIN) {
@@ -183,35 +199,58 @@ __device__ __forceinline__ void ws_stage_out(unsigned char* smem, int layer, int
   }
   *reinterpret_cast<u32x2*>(wrow + HOFF + ug * 16 + hh * 8) = u32x2{hpk[0], hpk[1]};
 }
-// stores of wave `wave` for the item staged in iteration ip: 2 (h) + TRAIN 4 (gates, c) store instructions, every path
+// flush of staging generation g (iteration g): layer-2 outputs of item g, layer-1 outputs of item g - 1 (layer 1 runs its
+// cell update one iteration late, see the kernel).  Done by the four layer-2 waves, wave ug rows [8 ug, 8 ug + 8) of both
+// layers: reads first (ws_flush_read: LDS -> registers, bumps the readers-done counter), then the stores
+// (ws_flush_store: per layer 1 (h) + TRAIN 3 (gates x 2, c) store instructions, on every path).
+struct WsFlush { u32x4 g[2][2]; u32x4 c[2]; u32x4 h[2]; };
 template <bool TRAIN>
-__device__ __forceinline__ void ws_flush(unsigned char* smem, int wave, int lane, int ip, int row0, int cu, __amdgpu_buffer_rsrc_t h1r,
-                                         __amdgpu_buffer_rsrc_t h2r, __amdgpu_buffer_rsrc_t g1r, __amdgpu_buffer_rsrc_t g2r,
-                                         __amdgpu_buffer_rsrc_t c1r, __amdgpu_buffer_rsrc_t c2r) {
+__device__ __forceinline__ void ws_flush_read(WsFlush& f, unsigned char* smem, int ug, int lane, int gen) {
   constexpr int STROW = TRAIN ? WS_STROW_TRN : WS_STROW_INF;
   constexpr int HOFF = TRAIN ? 320 : 0;
   asm volatile("" : "+v"(lane));        // (see ws_stage_out)
 #pragma unroll
   for (int layer = 0; layer < 2; ++layer) {
-    const unsigned char* stg = ws_stg<TRAIN>(smem, layer, ip & 1);
+    const unsigned char* stg = ws_stg<TRAIN>(smem, layer, gen & 1);
     if (TRAIN) {
-      const int r = 4 * wave + (lane >> 4), col = lane & 15;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + col * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(v, layer ? g2r : g1r, (row0 + r) * (WS_H * 8) + cu * 256 + col * 16, 0, 2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        f.g[layer][k] = *reinterpret_cast<const u32x4*>(stg + (8 * ug + 4 * k + (lane >> 4)) * STROW + (lane & 15) * 16);
     }
-    const int r = 4 * wave + ((lane & 15) >> 2), col = lane & 3;
-    const int goff = lane < 16 ? (row0 + r) * WS_HB + cu * 64 + col * 16 : 0x7ffffff0;   // lanes 16-63: out of range, dropped
-    if (TRAIN) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + 256 + col * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(v, layer ? c2r : c1r, goff, 0, 2);
-    }
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * STROW + HOFF + col * 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, layer ? h2r : h1r, goff, 0, 16);
+    const int r = 8 * ug + ((lane & 31) >> 2), col = lane & 3;
+    if (TRAIN) f.c[layer] = *reinterpret_cast<const u32x4*>(stg + r * STROW + 256 + col * 16);
+    f.h[layer] = *reinterpret_cast<const u32x4*>(stg + r * STROW + HOFF + col * 16);
   }
   if (TRAIN && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(smem + WS_OFF_CNT), 1u);
 }
+template <bool TRAIN>
+__device__ __forceinline__ void ws_flush_store(const WsFlush& f, int layer, int ug, int lane, int row0, int cu, __amdgpu_buffer_rsrc_t hr,
+                                               __amdgpu_buffer_rsrc_t gr, __amdgpu_buffer_rsrc_t cr) {
+  asm volatile("" : "+v"(lane));
+  if (TRAIN) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(f.g[layer][k], gr,
+                                             (row0 + 8 * ug + 4 * k + (lane >> 4)) * (WS_H * 8) + cu * 256 + (lane & 15) * 16, 0, 2);
+  }
+  const int r = 8 * ug + ((lane & 31) >> 2), col = lane & 3;
+  const int goff = lane < 32 ? (row0 + r) * WS_HB + cu * 64 + col * 16 : 0x7ffffff0;     // lanes 32-63: out of range, dropped
+  if (TRAIN) __builtin_amdgcn_raw_buffer_store_b128(f.c[layer], cr, goff, 0, 2);
+  __builtin_amdgcn_raw_buffer_store_b128(f.h[layer], hr, goff, 0, 16);
+}
 
 __device__ __forceinline__ bf16x8 lds_frag(const lds_u8* p) { return *reinterpret_cast<const bf16x8*>(p); }
+#ifdef WS_DIAG_NOMFMA
+// diagnostic build: the matrix pipe is not used (one VALU instruction keeps the operands alive)
+__device__ __forceinline__ f32x16 ws_mfma(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  c[0] += __builtin_bit_cast(f32x4, a)[0] * __builtin_bit_cast(f32x4, b)[0];
+  return c;
+}
+#else
+__device__ __forceinline__ f32x16 ws_mfma(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
 template <bool TRAIN>
 __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
@@ -259,10 +298,10 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       a.cst + (((size_t)cluster * WS_G + cu) * a.nch_max * 2 + layer) * 4 * 256 + ug * 256, 0, (unsigned)a.nch_max * 2 * 4 * 256 * 4, 0x00020000);
 
   auto mk_item = [&](int s_, int c_) {
-    WsItem it;
-    it.s = s_;
-    it.c = c_;
-    it.row0 = (long)(cluster + (long)c_ * a.clusters) * WS_MC;
+    WsItem it;                                                     // readfirstlane: provably wave-uniform (SGPRs, no waterfall
+    it.s = __builtin_amdgcn_readfirstlane(s_);                     // loops around the buffer accesses that take them as offsets)
+    it.c = __builtin_amdgcn_readfirstlane(c_);
+    it.row0 = __builtin_amdgcn_readfirstlane((cluster + c_ * a.clusters) * WS_MC);
     return it;
   };
   auto next_item = [&](const WsItem& it) { return it.c + 1 < nch ? mk_item(it.s, it.c + 1) : mk_item(it.s + 1, 0); };
@@ -277,17 +316,26 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
 #ifdef WS_STAMP
   const bool st_on = cluster == 0 && cu == 0 && ug == 0;
 #endif
-  // stores of the item staged in iteration ip (fused step sp, chunk row0p): h1 of time sp, h2 / layer-2 state of time sp - 1
-  auto flush = [&](int ip, const WsItem& pit) {
-    const int sp = pit.s;
-    const bool a1 = sp < Tn, a2 = sp >= 1 && sp <= Tn;
-    ws_flush<TRAIN>(smem, wave, lane, ip, (int)pit.row0, cu, ws_rsrc(a.h1, slot(sp), N, WS_HB, a1),
-                    ws_rsrc(a.h2, slot(sp - 1), N, WS_HB, a2), ws_rsrc(a.g1, sp, N, WS_H * 8, a1 && TRAIN),
-                    ws_rsrc(a.g2, sp - 1, N, WS_H * 8, a2 && TRAIN), ws_rsrc(a.c1, sp, N, WS_HB, a1 && TRAIN),
-                    ws_rsrc(a.c2, sp - 1, N, WS_HB, a2 && TRAIN));
+  // flush of generation g: layer 1 staged item i1 (h1 / gates / c of time s), layer 2 item i2 (state of time s - 1)
+  auto flush_store = [&](const WsFlush& f, const WsItem& i1, const WsItem& i2, bool v1, bool v2) {
+    const bool a1 = v1 && i1.s < Tn, a2 = v2 && i2.s >= 1 && i2.s <= Tn;
+    ws_flush_store<TRAIN>(f, 0, ug, lane, i1.row0, cu, ws_rsrc(a.h1, slot(i1.s), N, WS_HB, a1),
+                          ws_rsrc(a.g1, i1.s, N, WS_H * 8, a1 && TRAIN), ws_rsrc(a.c1, i1.s, N, WS_HB, a1 && TRAIN));
+    ws_flush_store<TRAIN>(f, 1, ug, lane, i2.row0, cu, ws_rsrc(a.h2, slot(i2.s - 1), N, WS_HB, a2),
+                          ws_rsrc(a.g2, i2.s - 1, N, WS_H * 8, a2 && TRAIN), ws_rsrc(a.c2, i2.s - 1, N, WS_HB, a2 && TRAIN));
   };
+  // Schedule of one iteration i (between two workgroup barriers), the two waves of a SIMD alternating between the matrix
+  // pipe and the vector / memory pipes:
+  //   layer-2 wave:  flush(i-1) | GEMM_2(i) ................... | poll, cell update_2(i), stage-out
+  //   layer-1 wave:  gather(i+1) issue, cell update_1(i-1), stage-out, head | GEMM_1(i) | tile(i+1) -> LDS
+  // i.e. layer 1 runs its cell update one iteration late (its accumulators survive the barrier): it overlaps the other wave's
+  // GEMM instead of competing with it for the vector issue, and its own GEMM runs beside the other wave's cell update.
+  // Outputs: staging generation i holds layer 2 of item i and layer 1 of item i - 1; the layer-2 waves flush it at the top of
+  // iteration i + 1 and wait for those stores in front of that iteration's barrier: the stores of item j are complete before
+  // barrier j + 2 and flag j rises behind it; the flags of item i + 2 are polled in iteration i: a cluster needs at least 5
+  // chunks.
   if (layer == 0) {
-    // =============================== layer-1 waves: staging + layer 1 + head ===============================
+    // =============================== layer-1 waves: gather + layer 1 + head ===============================
     bf16x8 w[WS_NK1];
     {
       const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.wp1) + ((size_t)(cu * 4 + ug) * WS_NK1) * 512 + lane * 8;
@@ -295,7 +343,7 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       for (int ks = 0; ks < WS_NK1; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 512);
       __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): no per-item waits for the weight loads
     }
-    // staging pattern: waves 0,1 gather h1 rows [16 (ug & 1), +16), waves 2,3 the same rows of h2: 768 16-byte chunks =
+    // gather pattern: waves 0,1 take h1 rows [16 (ug & 1), +16), waves 2,3 the same rows of h2: 768 16-byte chunks =
     // 12 per lane, chunk idx = lane + 64 j -> (row idx / 48, column idx % 48); the pattern repeats every 3 j with 4 rows more
     int sv[3], dv[3];
 #pragma unroll
@@ -307,18 +355,11 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
     const int xdv = (8 * ug + (lane >> 3)) * WS_ROWB + (lane & 7) * 16;
 
     u32x4 st[13];
-    // gather of item `it` (no poll here: wave 4 has seen the flags of this item before the barrier this wave has passed)
-    auto stage_issue = [&](const WsItem& it) {
-      const int th = (ug >> 1) ? it.s - 2 : it.s - 1;              // time of the h rows this wave gathers
-      const __amdgpu_buffer_rsrc_t hr = ws_rsrc((ug >> 1) ? a.h2 : a.h1, slot(th), N, WS_HB, th >= 0 && th < Tn);
-      const int so = (int)(it.row0 + 16 * (ug & 1)) * WS_HB;
-#pragma unroll
-      for (int j = 0; j < 12; ++j)
-        st[j] = __builtin_amdgcn_raw_buffer_load_b128(hr, sv[j % 3], so + (j / 3) * 4 * WS_HB, 16);
-      const __amdgpu_buffer_rsrc_t xr = ws_rsrc(a.x, it.s, N, WS_KX * 2, it.s < Tn);
-      st[12] = __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, (int)(it.row0 + 8 * ug) * WS_KX * 2, 0);
-    };
     auto stage_write = [&](int buf) {
+#ifdef WS_DIAG_NOTILEWRITE
+      asm volatile("" :: "v"(st[0]), "v"(st[12]));
+      return;
+#endif
       unsigned char* t = smem + buf * WS_TILEB;
 #pragma unroll
       for (int j = 0; j < 12; ++j) *reinterpret_cast<u32x4*>(t + dv[j % 3] + (j / 3) * 4 * WS_ROWB) = st[j];
@@ -326,22 +367,73 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
     };
 
     __syncthreads();                                               // biases / head weights in LDS
-    WsItem it = mk_item(0, 0), itn = next_item(it), itp = it;
-    stage_issue(it);
-    stage_write(0);
-    f32x4 cc = {0.f, 0.f, 0.f, 0.f};                               // cell state of the current item (s = 0: zero)
+    WsItem it = mk_item(0, 0), itn = next_item(it), itp = it, itpp = it;
+    {
+      // tile of item 0: x_0 and zeros
+      const __amdgpu_buffer_rsrc_t xr = ws_rsrc(a.x, 0, N, WS_KX * 2, true);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) st[j] = u32x4{0u, 0u, 0u, 0u};
+      st[12] = __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, (it.row0 + 8 * ug) * WS_KX * 2, 0);
+      stage_write(0);
+    }
+    f32x16 acc;                                                    // gates of the previous item (cell update pending)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 ccp = {0.f, 0.f, 0.f, 0.f};                              // its cell state
     __syncthreads();
     WST_INIT
-
 #pragma unroll 1
     for (int i = 0; i < nitems; ++i) {
       const int buf = i & 1;
       const bool more = i + 1 < nitems;
-      if (i >= 1) flush(i - 1, itp);                                // the previous item's outputs: oldest stores of this iteration
+      WST(5)
+      // ---- gather of the NEXT item (its flags were seen by wave 4 before the barrier just passed): 13 x 1 KB per wave, in
+      // flight during the cell update and the GEMM below
+      {
+        const int th = (ug >> 1) ? itn.s - 2 : itn.s - 1;            // time of the h rows this wave gathers
+        const __amdgpu_buffer_rsrc_t ghr = ws_rsrc((ug >> 1) ? a.h2 : a.h1, slot(th), N, WS_HB, more && th >= 0 && th < Tn);
+        const __amdgpu_buffer_rsrc_t gxr = ws_rsrc(a.x, itn.s, N, WS_KX * 2, more && itn.s < Tn);
+#ifdef WS_DIAG_GATHERL2
+        const int gso = (16 * (ug & 1)) * WS_HB;      // diagnostic: always the same rows (L2 hits instead of freshly published lines)
+#else
+        const int gso = (itn.row0 + 16 * (ug & 1)) * WS_HB;
+#endif
+#ifndef WS_DIAG_NOGATHER
+#pragma unroll
+        for (int j = 0; j < 12; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ghr, sv[j % 3], gso + (j / 3) * 4 * WS_HB, 16);
+        st[12] = __builtin_amdgcn_raw_buffer_load_b128(gxr, lane * 16, (itn.row0 + 8 * ug) * WS_KX * 2, 0);
+#else
+#pragma unroll
+        for (int j = 0; j < 13; ++j) st[j] = u32x4{(unsigned)gso, 0u, 0u, 0u};
+#endif
+      }
+#ifdef WS_STAMP
       __builtin_amdgcn_sched_barrier(0);
-      // ---- head of time s - 2 from the full h2_{s-2} in the tile: waves 2, 3 of the chunk's designated CU.  FIRST in the
-      // iteration: its (conditional) stores must be older than the gather below, so that the waits for the gather can be
-      // counted ones that leave this item's unconditional stores in flight
+      WST(6)
+#endif
+      // ---- cell update of item i - 1 (layer 1 of its time s), executed for every item: the steps behind the last time
+      // step compute on zeros and are stored through an empty descriptor (no store sits in a conditional path)
+      {
+        unsigned hpk[2], cpk[2];
+        u32x4 gpk[2];
+        if (itp.s == 0) ccp = f32x4{0.f, 0.f, 0.f, 0.f};
+        ws_cell<TRAIN>(acc, ccp, hpk, gpk, cpk);
+        cst_store(itp, ccp);
+        ws_stage_out<TRAIN>(smem, 0, ug, lane, i, hpk, gpk, cpk);
+      }
+#ifndef WS_STAMP
+      // spread the 13 gather loads over the cell update (issued in one burst, the 52 loads of the four gathering waves fill the
+      // CU's vector-memory queue and every wave blocks at the issue for most of the 830 cycles the 52 KB take at 64 B/clk)
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      WST(0)
+      // ---- head of time s - 2 from the full h2_{s-2} in the tile: waves 2, 3 of the chunk's designated CU.  Its
+      // (conditional) stores must be older than the gather below, so that the waits for the gather can be counted ones
       if (a.whp && ug >= 2 && it.s >= 2 && (it.c + it.s) % WS_G == cu) {
         const int n16 = lane & 15, q = lane >> 4, half = ug - 2;
         const lds_u8* bp = ltile + buf * WS_TILEB + (16 * half + n16) * WS_ROWB + (WS_KX + WS_H) * 2 + q * 16;
@@ -356,16 +448,12 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           if (4 * q + j < a.O) __builtin_nontemporal_store(hacc[j], hp + 4 * q + j);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // next item's cell state (older than everything below: waiting for it never waits for this item's stores)
-      f32x4 ccn = cst_load(itn);
+      // cell state of THIS item (its update runs in the next iteration)
+      f32x4 cc = cst_load(it);
       __builtin_amdgcn_sched_barrier(0);
-      WST(0)
+      WST(1)
       {
-        // ---- layer 1 of time s: gates = W1 . [x_s | h1_{s-1}]^T + b.  Executed for EVERY item (the steps behind the last
-        // time step compute on zeros and store through an empty descriptor): no store sits in a conditional path.
-        // The gather of the NEXT item is issued between the MFMAs, one 1 KB load per two k-steps: issued in one burst the
-        // 56 loads of the four staging waves fill the CU's vector-memory queue and every wave blocks at the issue
-        f32x16 acc;
+        // ---- layer 1 of time s: gates = W1 . [x_s | h1_{s-1}]^T + b
         {
           const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (ug * 8 + 4 * hh) * 16;
 #pragma unroll
@@ -375,63 +463,42 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           }
         }
         const lds_u8* bp = ltile + buf * WS_TILEB + boff;
-        const int th = (ug >> 1) ? itn.s - 2 : itn.s - 1;            // time of the h rows this wave gathers
-        const __amdgpu_buffer_rsrc_t ghr = ws_rsrc((ug >> 1) ? a.h2 : a.h1, slot(th), N, WS_HB, more && th >= 0 && th < Tn);
-        const __amdgpu_buffer_rsrc_t gxr = ws_rsrc(a.x, itn.s, N, WS_KX * 2, more && itn.s < Tn);
-        const int gso = (int)(itn.row0 + 16 * (ug & 1)) * WS_HB;
         bf16x8 b[WS_PF];
 #pragma unroll
         for (int d = 0; d < WS_PF; ++d) b[d] = lds_frag(bp + d * 32);
 #pragma unroll
         for (int ks = 0; ks < WS_NK1; ++ks) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b[ks % WS_PF], acc, 0, 0, 0);
+          acc = ws_mfma(w[ks], b[ks % WS_PF], acc);
           if (ks + WS_PF < WS_NK1) b[ks % WS_PF] = lds_frag(bp + (ks + WS_PF) * 32);
-          if ((ks & 1) && (ks >> 1) < 12) {
-            const int j = ks >> 1;
-            st[j] = __builtin_amdgcn_raw_buffer_load_b128(ghr, sv[j % 3], gso + (j / 3) * 4 * WS_HB, 16);
-          }
-          if (ks == 25) st[12] = __builtin_amdgcn_raw_buffer_load_b128(gxr, lane * 16, (int)(itn.row0 + 8 * ug) * WS_KX * 2, 0);
         }
         // pin the software pipeline (left alone, the scheduler sinks every LDS read to just in front of its MFMA and the
-        // wave pays the LDS latency once per two MFMAs): bias + first WS_PF reads, then one read (and every other step one
-        // gather load) behind each MFMA
+        // wave pays the LDS latency once per two MFMAs): bias + first WS_PF reads, then one read behind each MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 4 + WS_PF, 0);
 #pragma unroll
         for (int ks = 0; ks < WS_NK1; ++ks) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (ks & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        WST(1)
-        unsigned hpk[2], cpk[2];
-        u32x4 gpk[2];
-        if (it.s == 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
-        ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
-        cst_store(it, cc);
-        ws_stage_out<TRAIN>(smem, 0, ug, lane, i, hpk, gpk, cpk);
       }
       __builtin_amdgcn_sched_barrier(0);
       WST(2)
-      // every store of item i - 1 is complete once this wait for the gather has passed: the gather was issued behind them and
-      // a wave's vector-memory operations retire in order
       stage_write(buf ^ 1);
-      cc = ccn;                                                    // (the wait for ccn is older still)
+      ccp = cc;
       WST(3)
       ws_barrier();
       WST(4)
-      if (tid == 0 && i >= 1)
-        __hip_atomic_store(flags + itp.c * 16 + cu, (unsigned)(itp.s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && i >= 2)
+        __hip_atomic_store(flags + itpp.c * 16 + cu, (unsigned)(itpp.s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      itpp = itp;
       itp = it;
       it = itn;
       itn = next_item(itn);
     }
-    flush(nitems - 1, itp);                                         // (the last item's barrier has been passed)
+    // (the cell update of the last item is beyond the last time step: nothing to store)
     WST_FINI(0)
   } else {
     // =============================== layer-2 waves (wave 4 also polls) ===============================
-    // waves 4-7 are the younger half of the workgroup and lose the issue arbitration against the layer-1 wave on their
-    // SIMD (MI355X_MICROARCH, two waves per SIMD, items 2 and 4) although theirs is the longer chain: static priority
-    if (a.prio) __builtin_amdgcn_s_setprio(1);
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);                 // diagnostic switch (NPPC_WS_PRIO)
     constexpr int NKR = WS_NK2 - WS_NKL;                             // k-steps with register-resident weights: NKL .. 47
     bf16x8 w[NKR];
     {
@@ -446,23 +513,35 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
     }
     const lds_u8* wl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_W2L + (ug * WS_NKL * 64 + lane) * 16;
     __syncthreads();
-    WsItem it = mk_item(0, 0), itn = next_item(it), it2 = next_item(itn), itp = it;
+    WsItem it = mk_item(0, 0), itn = next_item(it), it2 = next_item(itn), itp = it, itpp = it;
     __syncthreads();
     WST_INIT
 #pragma unroll 1
     for (int i = 0; i < nitems; ++i) {
       const int buf = i & 1;
       const int t = it.s - 1;
-      if (i >= 1) flush(i - 1, itp);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 cc = cst_load(it);
-      // wave 4: the flags of item i + 2 (its gather starts right behind this iteration's barrier): requested here, looked
-      // at behind the GEMM.  Every CU of the cluster must have published item (c, s - 1).
+      WST(6)
+      // wave 4: the flags of item i + 2 (its gather starts right behind this iteration's barrier): requested FIRST (older than
+      // the flush stores below: the wait for them never covers a write-through store), looked at behind the GEMM.
+      // Every CU of the cluster must have published item (c, s - 1).
       const bool polls = ug == 0 && i + 2 < nitems && it2.s >= 1;
       unsigned pv = 0xffffffffu;
       if (polls && lane < WS_G) pv = __hip_atomic_load(flags + it2.c * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f32x4 cc = cst_load(it);
       __builtin_amdgcn_sched_barrier(0);
-      const bool active = it.s >= 1 && it.s <= Tn;
+      // ---- outputs of the previous generation: staging -> registers -> global, by the layer-2 waves (the shorter chain of
+      // an iteration).  Oldest stores of the iteration: complete long before the counted wait in front of the barrier
+      {
+#ifndef WS_DIAG_NOFLUSH
+        WsFlush fl;
+        ws_flush_read<TRAIN>(fl, smem, ug, lane, i - 1);
+        flush_store(fl, itpp, itp, i >= 2, i >= 1);
+#else
+        if (TRAIN && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(smem + WS_OFF_CNT), 1u);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      WST(0)
       // ---- layer 2 of time s - 1: gates = W2 . [h1_{s-1} | h2_{s-2}]^T + b (every item: see layer 1)
       f32x16 acc;
       {
@@ -489,12 +568,12 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
         for (int ks = 0; ks < WS_NK2; ++ks) {
           if (ks < WS_NKL) {
             const int e = 2 * ks;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r[e % WS_PF], r[(e + 1) % WS_PF], acc, 0, 0, 0);
+            acc = ws_mfma(r[e % WS_PF], r[(e + 1) % WS_PF], acc);
             if (e + WS_PF < E) r[e % WS_PF] = rd(e + WS_PF);
             if (e + 1 + WS_PF < E) r[(e + 1) % WS_PF] = rd(e + 1 + WS_PF);
           } else {
             const int e = WS_NKL + ks;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks - WS_NKL], r[e % WS_PF], acc, 0, 0, 0);
+            acc = ws_mfma(w[ks - WS_NKL], r[e % WS_PF], acc);
             if (e + WS_PF < E) r[e % WS_PF] = rd(e + WS_PF);
           }
         }
@@ -507,7 +586,6 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
         }
       }
       WST(1)
-      // the poll BEFORE this item's stores: the wait for the flag words then never covers a write-through store
       if (polls) {
         unsigned spins = 0;
         while (__builtin_amdgcn_ballot_w64(pv < (unsigned)it2.s) != 0) {
@@ -522,28 +600,36 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       WST(2)
+      if (a.prio == 2) __builtin_amdgcn_s_setprio(3);
       {
         unsigned hpk[2], cpk[2];
         u32x4 gpk[2];
         if (t <= 0) cc = f32x4{0.f, 0.f, 0.f, 0.f};
         ws_cell<TRAIN>(acc, cc, hpk, gpk, cpk);
+        WST(7)
         cst_store(it, cc);
         ws_stage_out<TRAIN>(smem, 1, ug, lane, i, hpk, gpk, cpk);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // the stores of item i - 1 (flushed at the top of this iteration) must be complete before this barrier, the flag of
-      // item i - 1 is raised behind it: leave only the cell-state store of THIS item in flight
+      // the flush stores of this iteration (generation i - 1: layer 2 of item i - 1, layer 1 of item i - 2) must be complete
+      // before the barrier, the flag of item i - 2 rises behind it: everything but this iteration's cell-state store
+      if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
       WST(3)
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       WST(4)
       ws_barrier();
       WST(5)
+      itpp = itp;
       itp = it;
       it = itn;
       itn = it2;
       it2 = next_item(it2);
     }
-    flush(nitems - 1, itp);
+    {
+      WsFlush fl;                                                  // the last generation (the last barrier has been passed)
+      ws_flush_read<TRAIN>(fl, smem, ug, lane, nitems - 1);
+      flush_store(fl, itpp, itp, true, true);
+    }
     WST_FINI(8)
   }
 }
@@ -594,14 +680,14 @@ extern "C" {
 
 // Plan of the weight-stationary forward for N sequences: clusters of 12 CUs and the largest number of 32-sequence chunks
 // one cluster walks; 0 clusters = not applicable (the caller uses the streaming kernels).  Needs whole chunks (N % 32 == 0)
-// and at least 4 chunks per cluster: the flag of item (c, s) is raised one item late and polled two items early, so with
+// and at least 5 chunks per cluster: the flag of item (c, s) is raised two items late and polled two items early, so with
 // fewer chunks a cluster would wait for itself.
 int nppc_lstm2_ws_plan(int prec, long N, int H, int I, int n_cu, int* clusters, int* nch_max) {
   *clusters = 0; *nch_max = 0;
   if (prec != NPPC_PREC_BF16 || H != WS_H || I > WS_KX || N <= 0 || N % WS_MC) return NPPC_OK;
   const long nchunks = N / WS_MC;
   long cl = n_cu / WS_G;
-  if (cl > nchunks / 4) cl = nchunks / 4;
+  if (cl > nchunks / 5) cl = nchunks / 5;
   if (cl < 1) return NPPC_OK;
   *clusters = (int)cl;
   *nch_max = (int)((nchunks + cl - 1) / cl);
@@ -637,7 +723,7 @@ int nppc_lstm2_fwd_ws(int train, const void* x, const void* wp1, const void* wp2
   if (whp && (!hpart || O < 1 || O > 16)) return NPPC_EBADARG;
   if (N % WS_MC) return NPPC_EUNSUPPORTED;
   const long nchunks = N / WS_MC;
-  if ((long)clusters * nch_max < nchunks || nchunks / clusters < 4 || N * (long)WS_H * 8 >= (1l << 31)) return NPPC_EBADARG;
+  if ((long)clusters * nch_max < nchunks || nchunks / clusters < 5 || N * (long)WS_H * 8 >= (1l << 31)) return NPPC_EBADARG;
   static const int prio = [] { const char* e = getenv("NPPC_WS_PRIO"); return e ? atoi(e) : 0; }();
   WsArgs a{x, wp1, wp2, bias1, bias2, h1, h2, g1, g2, c1, c2, cst, flags, whp, hpart, N, Tn, O, clusters, nch_max, (int)nchunks, prio};
   hipStream_t s = (hipStream_t)stream;

@@ -429,11 +429,11 @@ def test_handoff_timeout_counter_is_sticky():
     assert ops_lstm.coop_timeouts() == 0
 
 
-@pytest.mark.parametrize("N,Tn,train,O", [(128, 9, False, 2), (256, 7, True, 10), (416, 6, False, 4), (416, 5, True, 16),
-                                          (1024, 5, True, 10), (2688, 4, False, 2)])
+@pytest.mark.parametrize("N,Tn,train,O", [(160, 9, False, 2), (320, 7, True, 10), (512, 6, False, 4), (512, 5, True, 16),
+                                          (1280, 5, True, 10), (3360, 4, False, 2)])
 def test_weight_stationary_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train, O):
     """The 12-CU weight-stationary cluster kernel (csrc/lstm_ws.hip: weights in registers, one fused hand-off per time step,
-    chunks of 32 sequences walked round robin; 1, 2, 3 (ragged: 4/5/4 chunks), 8 and 21 clusters) against the single-workgroup
+    chunks of 32 sequences walked round robin; 1, 2, 3 (ragged: 6/5/5 chunks), 8 and 21 clusters) against the single-workgroup
     streaming kernel of the same precision and the oracle; head fused; no bounded spin may time out."""
     from nppc_audio import _hip as H
     from nppc_audio import ops_lstm

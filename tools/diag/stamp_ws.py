@@ -3,13 +3,14 @@
 import sys, os, subprocess, glob
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(root, "generative-audio_amd"))
-so = os.path.join(root, "tools", "diag", "libnppc_stampws.so")
+VAR = os.environ.get("WS_VARIANT", "")
+so = os.path.join(root, "tools", "diag", f"libnppc_stampws{VAR}.so")
 if "--build" in sys.argv:
     csrc = os.path.join(root, "generative-audio_amd", "csrc")
     objs = [os.path.join(root, "generative-audio_amd", "build", os.path.basename(f)[:-4] + ".o") for f in sorted(glob.glob(csrc + "/*.hip"))
             if not f.endswith("lstm_ws.hip")]
     o = "/tmp/lstm_ws_stamp.o"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DWS_STAMP", "-I" + os.path.join(root, "include"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DWS_STAMP", *[f"-D{d}" for d in os.environ.get("WS_DEFS", "").split()], "-I" + os.path.join(root, "include"),
                            "-I" + csrc, "-Wno-unused-value", "-c", os.path.join(csrc, "lstm_ws.hip"), "-o", o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, o] + objs)
     sys.exit(0)
@@ -30,8 +31,8 @@ def ws2(key, shape, dtype, device, zero=False):
         shape = (shape[0] + 64,)
     return orig(key, shape, dtype, device, zero)
 ops_lstm.workspace = ws2
-n1 = ["flush prev + head + cc prefetch", "bias + GEMM (28 MFMA) + gather issue", "pointwise + stage-out", "wait gather + LDS write", "barrier", "-", "-", "-"]
-n2 = ["-", "flush prev + bias + GEMM (48 MFMA)", "poll check", "pointwise + stage-out", "store drain (vmcnt)", "barrier", "-", "-"]
+n1 = ["stage-out", "head + cc load", "bias + GEMM (28 MFMA) + gather issue", "wait gather + LDS write", "barrier", "loop top (item shift)", "flush read + cell update(i-1)", "cell-state + flush stores"]
+n2 = ["poll + cc load issue", "bias + GEMM (48 MFMA)", "poll check", "cell-state store + stage-out", "-", "barrier", "loop top (item shift)", "cell update"]
 for N, train, O in ((8224, False, 2), (4096, True, 10), (4096, False, 10)):
     x = torch.randn(Tn, N, pk.kx, device=dev).to(torch.bfloat16); x[:, :, I:] = 0
     wh = torch.zeros(16, Hd, dtype=torch.bfloat16, device=dev); wh[:O] = (torch.randn(O, Hd) * 0.1).to(dev)
@@ -48,4 +49,4 @@ for N, train, O in ((8224, False, 2), (4096, True, 10), (4096, False, 10)):
         print(f"ws fwd N={N} train={train} {nm}: cycles/item {tot/nitems:.0f}  ({nitems} items, {tot/Tn:.0f} cycles/step)")
         for nme, v in zip(names, d):
             if nme != "-":
-                print(f"   {nme:40s} {v/nitems:9.1f}  {100*v/max(tot,1):5.1f}%")
+                print(f"   {nme:58s} {v/nitems:9.1f}  {100*v/max(tot,1):5.1f}%")
