@@ -349,7 +349,17 @@ __global__ void reduce_slabs_t_kernel(const float* __restrict__ slabs, int S, lo
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, no amsgrad)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                            float gscale, const double* __restrict__ sumsq, float max_norm) {
+                            float gscale, const double* __restrict__ sumsq, float max_norm,
+                            const unsigned* const* __restrict__ guards = nullptr, int n_guards = 0, float* poison = nullptr) {
+  // guards: sticky hand-off time-out counters of the cooperative LSTM kernels (csrc/lstm_coop.hip, lstm_ws.hip).  A
+  // non-zero one means some kernel of this step gave up on a partner and carried on with wrong numbers: the update is
+  // SKIPPED (parameters and moments stay bit-identical) and the step's objective is poisoned with NaN; the host raises
+  // at its next check.  Every workgroup reads the same few words: they cannot change while this kernel runs.
+  for (int i = 0; i < n_guards; ++i)
+    if (*guards[i] != 0u) {
+      if (poison && blockIdx.x == 0 && threadIdx.x == 0) *poison = __builtin_nanf("");
+      return;
+    }
   if (sumsq) {   // torch.nn.utils.clip_grad_norm_: coefficient max_norm / (||g|| + 1e-6), clamped to 1
     const float total = (float)sqrt(sumsq[0]) * gscale;
     const float coef = max_norm / (total + 1e-6f);
@@ -513,6 +523,22 @@ int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double 
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)b1, (float)b2,
                      (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale, (const double*)nullptr, 0.f);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// nppc_adam_step with the update guarded by device counters (guards: device array of n_guards device pointers to u32; the
+// update is skipped and *poison (nullable) set to NaN when any of them is non-zero): a hand-off time-out of a cooperative LSTM
+// kernel must not reach the weights in the steps between two host checks
+int nppc_adam_step_guarded(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                           double wd, int step, double gscale, const void* guards, int n_guards, float* poison, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1 || n_guards < 0 || (n_guards > 0 && !guards)) return NPPC_EBADARG;
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(b2, (double)step));
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)b1, (float)b2,
+                     (float)eps, (float)wd, (float)bc1, (float)bc2s, (float)gscale, (const double*)nullptr, 0.f,
+                     (const unsigned* const*)guards, n_guards, poison);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

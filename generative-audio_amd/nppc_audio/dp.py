@@ -36,6 +36,16 @@ class FlatGradientReducer:
         self._done.append((lo, hi))
         self._work.append(dist.all_reduce(gflat[lo:hi], group=self.group, async_op=True))
 
+    def reset(self):
+        """drop the bookkeeping of a step that did not finish (exception inside backward): wait for what is in flight"""
+        for w in self._work:
+            try:
+                w.wait()
+            except Exception:
+                pass
+        self._work.clear()
+        self._done.clear()
+
     def finish(self, gflat):
         """reduce what `range_ready` has not covered, wait for every bucket; returns the scale (1/world) that turns the
         summed buffer into the mean gradient"""

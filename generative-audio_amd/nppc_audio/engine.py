@@ -114,10 +114,13 @@ def unfold_multiplicity(F, nb):
 
 
 class FSNEngine:
-    # engines whose side-stream weight gradients have not been joined yet (defer_join mode).  A cooperative (CU-pair) LSTM
-    # kernel needs every CU for its own workgroups, so NOTHING of ours may be in flight on another stream when one is
-    # launched: forward / backward refuse to launch while this set is non-empty (the trainer's pre_lstm_hook empties it).
-    _unjoined = set()
+    # engines with side-stream work (weight gradients of a backward in defer_join mode, the re-pack of the updated weights)
+    # that the main stream has not been made to wait for yet.  A cooperative LSTM kernel needs every CU for its own
+    # workgroups, so NOTHING of ours may be in flight on another stream when one is launched: every engine joins ALL of them
+    # right before its LSTM launches (the trainer's pre_lstm_hook normally has done so already), and its OWN pending work
+    # at the top of forward / backward, before any kernel reads the packed weights the side stream may still be rewriting.
+    import weakref as _weakref
+    _unjoined = _weakref.WeakValueDictionary()
 
     def __init__(self, flat, *, num_freqs, n_maps, out_size, sb_neighbors, look_ahead, sb_hidden, groups, kersize,
                  prec, trainable):
@@ -141,13 +144,12 @@ class FSNEngine:
         self._gen = 0                         # train-forward generation: backward must consume the LATEST train forward
         self.last_train = None
         self.grad_range_hook = None           # fn(flat_grad, lo, hi): range final for this step (dp.FlatGradientReducer)
+        self.early_buckets_ok = self._check_bucket_layout() if trainable else False
         self.pre_lstm_hook = None             # one-shot callback run right before this engine's next LSTM launch (trainer)
         self.defer_join = False               # backward leaves the side-stream join to the caller (join_side)
         self.join_pending = False
         self.bufs = {}
         own_workspaces(self)                  # step-persistent workspaces keyed by id(self) die with the engine
-        import weakref
-        weakref.finalize(self, FSNEngine._unjoined.discard, id(self))
         self.lstm = PackedLSTM(self.I, self.Hd, prec, self.dev)
         self.KX = self.lstm.kx
         self.mult = torch.from_numpy(unfold_multiplicity(self.F, self.nb)).to(self.dev)
@@ -168,6 +170,28 @@ class FSNEngine:
             self.WfcT = torch.zeros(3, ldC, ldF, dtype=self.dt, device=self.dev)            # [c][f] = Wfc[f][c]
             self.WhT = torch.zeros(self.Hd, 32, dtype=self.dt, device=self.dev)             # [u][o] = Wh[o][u]
             self.gbuf = [None, None]
+
+    def _check_bucket_layout(self):
+        """the early gradient buckets (backward: the sub-band tail of the flat buffer; TCN blocks 4..7 of a branch) are
+        handed to the exchange as RANGES: true only when the flat buffer really has that layout -- everything from
+        sb_model.sequence_model.weight_ih_l0 to the end belongs to sb_model, and the range conv1x1.weight of block 4 ..
+        sconv.bias of block 7 of a branch holds nothing but that branch's blocks 4..7.  A subclass that registers parameters
+        elsewhere falls back to the single exchange in `finish` (no early bucket is announced)."""
+        off = self.fp.off
+        try:
+            t0 = off["sb_model.sequence_model.weight_ih_l0"][0]
+            if any(o >= t0 and not n.startswith("sb_model.") for n, (o, _) in off.items()):
+                return False
+            for br in BRANCHES:
+                a = off[f"fb_model{br}.sequence_model.4.conv1x1.weight"][0]
+                b, shp = off[f"fb_model{br}.sequence_model.7.sconv.bias"]
+                b += int(np.prod(shp))
+                pre = tuple(f"fb_model{br}.sequence_model.{i}." for i in (4, 5, 6, 7))
+                if any(a <= o < b and not n.startswith(pre) for n, (o, _) in off.items()):
+                    return False
+        except KeyError:
+            return False
+        return True
 
     # ------------------------------------------------------------------ weights
     def p(self, name):
@@ -265,6 +289,7 @@ class FSNEngine:
         B, _, F, T = maps[0].shape
         if B > 1:
             assert B > self.G, f"Batch size = {B}, num_groups = {self.G}."   # feature.py:263
+        self.join_side()                      # own side-stream work (re-pack of the updated weights) before anything reads it
         self.pack_weights()
         d = self._buffers(B, T, train)
         s = H.stream()
@@ -328,9 +353,7 @@ class FSNEngine:
             # (side-stream weight gradients, gradient exchange, Adam) here: it overlaps this net's small front kernels.
             hook, self.pre_lstm_hook = self.pre_lstm_hook, None
             hook()
-        if FSNEngine._unjoined:
-            raise RuntimeError("side-stream weight gradients of a previous backward are still in flight (defer_join): join "
-                               "them (NPPCAudioTrainer.flush / FSNEngine.join_side) before the next LSTM launch")
+        FSNEngine.join_all()                  # (a no-op after the trainer's hook; any other caller gets the join for free)
         lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
@@ -485,6 +508,7 @@ class FSNEngine:
         d = self.last_train
         if d is None or "lstm" not in d or "g1" not in d["lstm"]:
             raise RuntimeError("backward needs a forward(train=True) first")
+        FSNEngine.join_all()                  # the cooperative LSTM backward wants the chip to itself
         if gen is not None and gen != d["gen"]:
             raise RuntimeError(
                 f"direction-net backward for forward #{gen}, but forward #{d['gen']} has since overwritten the saved "
@@ -541,7 +565,7 @@ class FSNEngine:
         with torch.cuda.stream(self._side):
             self._lstm_wgrad(dg1, dg2, d["x_rows"], lo["h1_rows"], lo["h2_rows"], Tv, Nseq, head=head_wgrad,
                              guards=(lo["h1_guard"], lo["h2_guard"]) if "h1_guard" in lo else None)
-            if self.grad_range_hook is not None:
+            if self.grad_range_hook is not None and self.early_buckets_ok:
                 # the sub-band segment (LSTM + head: the tail of the flat buffer) is final once these GEMMs are done
                 self.grad_range_hook(G, self.fp.off["sb_model.sequence_model.weight_ih_l0"][0], G.numel())
         # ---- 4. staging backward -> gradient of the pre-ReLU full-band outputs
@@ -680,7 +704,7 @@ class FSNEngine:
                 H.call("nppc_gemm_nt", prec, EPI_RESIDUAL, h2b, TCN_HIDDEN, sAct, self.W1T[i], TCN_HIDDEN, ldC * TCN_HIDDEN, dXi, ldC,
                        R * ldC, None, 0, dXo, ldC, R * ldC, None, 0, None, 0, R, ldC, TCN_HIDDEN, Tp, Tv, C, 0, 3, 1, s)
             dXo, dXi = dXi, dXo
-            if i == 4 and self.grad_range_hook is not None:
+            if i == 4 and self.grad_range_hook is not None and self.early_buckets_ok:
                 # TCN blocks 7..4 of every branch are final once both queues have passed this point
                 def blocks_done():
                     for br in BRANCHES:
@@ -707,8 +731,8 @@ class FSNEngine:
         if fc_at_end:
             fc_wgrad(ws("slab_fc", (3 * S2 * Fr * ldC,), torch.float32))
         if self.defer_join:
-            self.join_pending = True          # the caller joins (join_side) before anything reads the gradient
-            FSNEngine._unjoined.add(id(self))
+            self.join_pending = True          # joined (join_side) before anything reads the gradient
+            FSNEngine._unjoined[id(self)] = self
         else:
             torch.cuda.current_stream().wait_stream(self._side)       # join the weight-gradient stream
         return G
@@ -725,11 +749,18 @@ class FSNEngine:
             self._side.wait_event(ev)
             self.pack_weights()
         self.join_pending = True
-        FSNEngine._unjoined.add(id(self))
+        FSNEngine._unjoined[id(self)] = self
 
     def join_side(self):
-        """make the current stream wait for the side-stream weight gradients of the last backward (defer_join mode)"""
+        """make the current stream wait for this engine's side-stream work (weight gradients of the last backward in
+        defer_join mode, re-packed weights); idempotent"""
         if self.join_pending:
             torch.cuda.current_stream().wait_stream(self._side)
             self.join_pending = False
-            FSNEngine._unjoined.discard(id(self))
+            FSNEngine._unjoined.pop(id(self), None)
+
+    @staticmethod
+    def join_all():
+        """make the current stream wait for the side-stream work of EVERY engine (before a cooperative LSTM launch)"""
+        for e in list(FSNEngine._unjoined.values()):
+            e.join_side()

@@ -91,6 +91,21 @@ def coop_timeouts():
     return _RETIRED_TIMEOUTS + sum(int(t[-4].item()) for t in _flag_blocks())
 
 
+_GUARDS = [None, ()]
+
+
+def timeout_guards():
+    """(device int64 tensor of the addresses of every live sticky time-out counter, count) for nppc_adam_step_guarded;
+    rebuilt only when the set of flag blocks changes (a host -> device copy of a few words)"""
+    blocks = _flag_blocks()
+    key = tuple(t.data_ptr() for t in blocks)
+    if _GUARDS[1] != key or _GUARDS[0] is None:
+        ptrs = [t[-4:].data_ptr() for t in blocks]
+        _GUARDS[0] = torch.tensor(ptrs or [0], dtype=torch.int64, device=blocks[0].device if blocks else "cuda")
+        _GUARDS[1] = key
+    return _GUARDS[0], len(blocks)
+
+
 def clear_coop_timeouts():
     global _RETIRED_TIMEOUTS
     _RETIRED_TIMEOUTS = 0
@@ -172,8 +187,10 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         # N zero guard rows in front (h_{-1} = 0): `h1_guard` row r is h1 row r - N, the B operand of the weight-gradient
         # product that pairs the gate gradients of step t with h_{t-1} without shifting the gate gradients
         Rp = padded_rows(Tn * N, N)
-        out["h1_guard"] = workspace(tag + ("h1",), (N + Rp, Hd), dt, dev, zero=True)
-        out["h2_guard"] = workspace(tag + ("h2",), (N + Rp, Hd), dt, dev, zero=True)
+        # (N, Tn) in the key: the guard rows in front and the padding rows behind Tn * N must be zero and are zeroed once per
+        # buffer; two (N, Tn) pairs with equal N + Rp must not share one (the larger N's guard rows would hold stale h)
+        out["h1_guard"] = workspace(tag + ("h1", N, Tn), (N + Rp, Hd), dt, dev, zero=True)
+        out["h2_guard"] = workspace(tag + ("h2", N, Tn), (N + Rp, Hd), dt, dev, zero=True)
         out["h1_rows"] = out["h1_guard"][N:]
         out["h2_rows"] = out["h2_guard"][N:]
         out["h1"] = rows_view(out["h1_rows"], Tn, N)

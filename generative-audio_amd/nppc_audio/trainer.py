@@ -193,14 +193,17 @@ class FlatAdamStepper:
             st["exp_avg"] = self.m[o:o + k].view(shp)
             st["exp_avg_sq"] = self.v[o:o + k].view(shp)
 
-    def step(self, gflat, grad_scale=1.0, clip=None):
-        """clip = (device double holding sum(g^2), max_norm): clip_grad_norm_ folded into the same kernel"""
+    def step(self, gflat, grad_scale=1.0, clip=None, poison=None):
+        """clip = (device double holding sum(g^2), max_norm): clip_grad_norm_ folded into the same kernel.
+        The plain update is guarded by the sticky hand-off time-out counters of the cooperative LSTM kernels: when one is
+        non-zero the kernel leaves parameters and moments untouched and writes NaN into `poison` (the step's objective)."""
         self.t += 1
         g = self.group
         b1, b2 = g["betas"]
         if clip is None:
-            H.call("nppc_adam_step", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]), float(b1),
-                   float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), H.stream())
+            guards, ng = ops_lstm.timeout_guards()
+            H.call("nppc_adam_step_guarded", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]), float(b1),
+                   float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), guards, ng, poison, H.stream())
         else:
             H.call("nppc_adam_step_clip", self.eng.fp.flat, gflat, self.m, self.v, gflat.numel(), float(g["lr"]),
                    float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), clip[0],
@@ -250,14 +253,21 @@ class NPPCAudioTrainer(nn.Module):
         else:
             self.optimizer = getattr(optim, okind)(self.nppc_model.parameters(), **config.optimizer_configuration.args)
         self._flat_adam = None
-        self._reducer = FlatGradientReducer()
+        # Data parallel: ONE all-reduce of the flat gradient on the main stream behind backward is the default; the bucketed
+        # exchange that starts inside backward (dp.py) and the parked update (pipeline_update) are opt-in
+        # (NPPC_DP_OVERLAP=1 / NPPC_DP_PIPELINE=1) until a multi-rank RCCL run of the bf16 step with the cooperative LSTM
+        # kernels is on record: RCCL's persistent kernels beside co-residency-dependent cooperative kernels is exactly what
+        # the one-GPU boxes of this pool cannot exercise.
+        self._reducer = FlatGradientReducer(overlap=os.environ.get("NPPC_DP_OVERLAP", "0") == "1")
         # pipeline_update: the tail of a step (side-stream weight gradients, the rest of the gradient exchange, Adam) is not
         # waited for at the end of train_step but parked in front of the NEXT step's restorer LSTM launch, so it overlaps
         # the next minibatch's STFTs and the frozen restorer's full-band front (which do not read the trained weights).
         # The update is applied before the direction net runs again: results are identical; parameters are current after
-        # flush() (train() flushes at every log interval and at the end, save_checkpoint() always).
+        # flush() (train() checks the hand-off time-out counter at every log interval and flushes at the end,
+        # save_checkpoint() always flushes).
         self.pipeline_update = False
         self._pending = None
+        self._poison = None
 
     # ---------------------------------------------------------------------------------- reference API
     def base_step(self, batch):
@@ -289,17 +299,23 @@ class NPPCAudioTrainer(nn.Module):
         if self._pending is not None:
             # the previous step's update goes out right before the restorer's LSTM launch of THIS step
             self.nppc_model.pretrained_restoration_model.engine().pre_lstm_hook = self.flush
+        ok = False
         try:
             reconst_err, objective, log = self.base_step(batch)
             self.flush()                                     # (no-op when the hook already ran)
             self.optimizer.zero_grad()
             objective.backward()
+            ok = True
         finally:
             net.flat_grad_only = False
             eng.grad_range_hook = None
             eng.defer_join = False
+            if not ok:
+                self._reducer.reset()                        # an exception inside backward must not leave buckets behind
         if fast:
             self._pending = eng
+            obj_d = objective.detach()
+            self._poison = obj_d if (obj_d.dtype == torch.float32 and obj_d.is_contiguous() and obj_d.is_cuda) else None
             if not defer:
                 self._apply_pending(prepack=PREPACK_AFTER_UPDATE)
         else:
@@ -330,7 +346,8 @@ class NPPCAudioTrainer(nn.Module):
         scale = self._reducer.finish(gflat)                  # sum over ranks; the mean's 1/W goes into Adam's grad scale
         if self._flat_adam is None or self._flat_adam.eng is not eng:
             self._flat_adam = FlatAdamStepper(self.optimizer, eng)
-        self._flat_adam.step(gflat, scale)
+        self._flat_adam.step(gflat, scale, poison=self._poison)
+        self._poison = None
         if prepack and eng.side_stream() is not None:
             # the bf16 / packed copies of the updated weights (0.2 ms of small launches at the top of the direction net's next
             # forward, i.e. on the critical path between the two forward LSTMs) go out NOW on the side stream: they overlap
@@ -344,7 +361,37 @@ class NPPCAudioTrainer(nn.Module):
         loop_loader = LoopLoader(dataloader=self.dataloader, n_steps=n_steps, n_epochs=n_epochs)
         log_every = log_every or self.config.log_interval
         log_dict = None
-        self.pipeline_update = self.world > 1      # hides the tail of the gradient exchange behind the next step's front
+        if len(loop_loader) == 0:
+            raise ValueError("the data loader yields no minibatch (fewer samples than one global batch?)")
+        # pipeline_update would hide the tail of the gradient exchange behind the next step's front: opt-in (see __init__)
+        self.pipeline_update = self.world > 1 and os.environ.get("NPPC_DP_PIPELINE", "0") == "1"
+        try:
+            self._train_loop(loop_loader, log_every)
+        finally:
+            self.pipeline_update = False
+        log_dict = self._last_log
+        timestamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+        if self.rank == 0 and log_dict is not None:
+            self._get_and_save_metrics(checkpoint_dir, log_dict, n_epochs, n_steps, timestamp)
+            self.save_checkpoint(os.path.join(checkpoint_dir, f"checkpoint_final_{timestamp}.pt"))
+
+    def _check_timeouts(self, where):
+        """the sticky hand-off time-out counter, agreed on by ALL ranks (a rank that raised alone would leave its peers
+        hanging in the next all-reduce): every rank raises when any rank counted one"""
+        n = ops_lstm.coop_timeouts()
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([n], dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if int(t.item()) and not n:
+                raise RuntimeError(f"cooperative LSTM hand-off time-out(s) on another rank at {where}: results since the "
+                                   "last check are invalid")
+        if n:
+            ops_lstm.check_coop_timeouts(where)
+
+    def _train_loop(self, loop_loader, log_every):
+        log_dict = None
+        self._last_log = None
         for it, batch in enumerate(loop_loader):
             if isinstance(batch, (tuple, list)):
                 batch = tuple(x.to(self.device, non_blocking=True) for x in batch)
@@ -355,17 +402,13 @@ class NPPCAudioTrainer(nn.Module):
                 # host syncs only every log_every steps (the reference does three .item() per step, trainer.py:107-113);
                 # the same sync point checks the sticky hand-off time-out counter of the cooperative LSTM kernels, on
                 # every rank: after a time-out the kernels continue with wrong numbers
-                ops_lstm.check_coop_timeouts(f"step {self.step}")
+                self._check_timeouts(f"step {self.step}")
             if self.rank == 0 and (it % log_every == 0 or it + 1 == len(loop_loader)):
                 print(f'step {self.step}: Objective: {objective.item():.4f} | '
                       f'Second Moment MSE: {log_dict["second_moment_mse"].mean().item():.4f} | '
                       f'Reconstract Error: {reconst_err.mean().item():.4f}')
+            self._last_log = log_dict
         self.flush()
-        self.pipeline_update = False
-        timestamp = datetime.now().strftime("%Y%m%d_%H%M%S")
-        if self.rank == 0 and log_dict is not None:
-            self._get_and_save_metrics(checkpoint_dir, log_dict, n_epochs, n_steps, timestamp)
-            self.save_checkpoint(os.path.join(checkpoint_dir, f"checkpoint_final_{timestamp}.pt"))
 
     def _get_and_save_metrics(self, checkpoint_dir, log_dict, n_epochs, n_steps, timestamp):
         ds = self.config.data_configuration.dataset
@@ -405,7 +448,9 @@ class ShardedBatchSampler(torch.utils.data.Sampler):
         self.epoch = 0
 
     def __len__(self):
-        return self.n // self.gb          # the ragged tail is dropped (__iter__), so every rank has equal work
+        # world > 1: the ragged tail is dropped so that every rank has equal work; one rank keeps it like the reference's
+        # DataLoader(drop_last=False) does (nppc_audio/trainer.py:54-60): n_epochs -> steps then agree with the reference
+        return self.n // self.gb if self.world > 1 else (self.n + self.gb - 1) // self.gb
 
     def __iter__(self):
         if self.shuffle:
@@ -415,6 +460,10 @@ class ShardedBatchSampler(torch.utils.data.Sampler):
             order = list(range(self.n))
         self.epoch += 1
         per = self.gb // self.world
+        if self.world == 1:
+            for b0 in range(0, self.n, self.gb):
+                yield order[b0:b0 + self.gb]
+            return
         for b0 in range(0, self.n - self.gb + 1, self.gb):     # drop the ragged tail so every rank has equal work
             glob = order[b0:b0 + self.gb]
             yield glob[self.rank * per:(self.rank + 1) * per]

@@ -281,6 +281,11 @@ int nppc_loss_bwd_coef_dev(const double* coefA, const double* coefE, const float
 /* ---- optimizer: torch.optim.Adam (nppc_audio/trainer.py:64-69,102-104) -------------------------------------- */
 int nppc_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                    double wd, int step, double gscale, void* stream);
+/* the same, guarded: `guards` = device array of n_guards device pointers to the sticky hand-off time-out counters of the
+ * cooperative LSTM launches; if any is non-zero the update is skipped (p, m, v untouched) and *poison (nullable, the step's
+ * objective) becomes NaN -- wrong numbers never reach the weights between two host checks of the counters */
+int nppc_adam_step_guarded(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                           double wd, int step, double gscale, const void* guards, int n_guards, float* poison, void* stream);
 
 /* ---- on-device batch synthesis (dataset/audio_dataset.py:92-152: dBFS normalisation, SNR mix, clip guard) -------
  * target_item (nullable): per-clip normalisation level [B] in dBFS (the reference's target_dB_FS_floating_value > 0

@@ -71,6 +71,11 @@ def test_cirm_build_decompress_dropband(name):
         ops.drop_band(x[:2], 2)
 
 
+# error / max|reference| of the intermediate taps; measured worst over the fixtures (profiles/r03_parity_errors.json):
+# fp32 att 8.8e-5 (imag branch: laplace norm of a signed map), fb 8.8e-5, sb 1.1e-6; bf16 att 3.3e-3, fb 7.0e-3, sb 4.8e-3
+TAP_LIMITS = {"fp32": {"att": 3e-4, "fb": 3e-4, "sb": 1e-5}, "bf16": {"att": 1e-2, "fb": 2e-2, "sb": 1.5e-2}}
+
+
 def _restorer(c, precision):
     from nppc_audio.fullsubnet import FullSubNet_Plus, FullSubNetPlusConfig
     cfg = FullSubNetPlusConfig(num_freqs=c["F"], sb_num_neighbors=c["sbn"], sb_model_hidden_size=c["sbh"],
@@ -84,9 +89,9 @@ def _restorer(c, precision):
 
 
 @pytest.mark.parametrize("name,precision,tol", [("g0_tiny", "fp32", 3e-4), ("g1_c1", "fp32", 3e-4),
-                                                ("g2_k5", "fp32", 3e-4), ("g1_c1", "bf16", 6e-2),
-                                                ("g0_tiny", "bf16", 6e-2)])
-def test_restorer_forward_matches_reference(name, precision, tol):
+                                                ("g2_k5", "fp32", 3e-4), ("g1_c1", "bf16", 3e-2),
+                                                ("g0_tiny", "bf16", 3e-2)])
+def test_restorer_forward_matches_reference(name, precision, tol, record_err):
     z, meta = load(name)
     c = meta["config"]
     net = _restorer(c, precision)
@@ -109,7 +114,16 @@ def test_restorer_forward_matches_reference(name, precision, tol):
     report["out"] = rel(out.cpu().numpy(), z["pred_crm_full"])
     print(name, precision, report)
     assert out.shape == z["pred_crm_full"].shape
-    assert report["out"] < tol, report
+    record_err("out", report["out"], tol)
+    # intermediate taps (rows a5 / a6 / a8 / a9 / a10), asserted: attention-scaled maps, full-band outputs, the staged
+    # sub-band LSTM input (unfold + concat + laplace norm + drop-band order).  Limits = stated multiples of what
+    # profiles/r03_parity_errors.json records; real / imag branches are the ill-conditioned ones (hard part b)
+    lim = TAP_LIMITS[precision]
+    for tag in ("att_mag", "att_real", "att_imag"):
+        record_err(tag, report[tag], lim["att"])
+    for tag in ("fb_mag", "fb_real", "fb_imag"):
+        record_err(tag, report[tag], lim["fb"])
+    record_err("sb_in_head", report["sb_in_head"], lim["sb"])
     # fp32 tolerance note: reference fp32-vs-fp64 floor for pred_crm is 1.2e-5; the laplace
     # norm of the signed real/imag maps amplifies summation-order differences (hard part b)
 
@@ -173,3 +187,26 @@ def test_pc_direction_spectrograms_and_waveforms():
         for ai, a in enumerate(alphas):
             ref = R.istft_wave(e_re + a * r_ref, e_im + a * i_ref, c["nfft"], c["hop"], L).numpy()
             assert rel(var[:, k, ai].cpu().numpy(), ref) < 5e-5
+
+
+def test_validator_synthesis_matches_reference_golden():
+    """row f1 / a22 pinned to the REFERENCE: crm_directions_to_spectrograms, model_outputs_to_waveforms (one iSTFT) and
+    pc_direction_waveforms (all alpha variations as one batched iSTFT launch) against tests/golden/validator_f1.npz = outputs of
+    the reference's own utils.model_outputs_to_waveforms / utils.crm_to_spectogram / torch.istft (make_goldens_validator.py)."""
+    import os
+    from golden_util import GOLD
+    from nppc_audio import ops
+    v = np.load(os.path.join(GOLD, "validator_f1.npz"))
+    z, _ = load("g1_c1")
+    n_re, n_im = torch.from_numpy(z["noisy_real"]).cuda(), torch.from_numpy(z["noisy_imag"]).cuda()      # [B,1,F,T]
+    pred = torch.from_numpy(z["pred_crm_full"]).cuda()
+    L = z["noisy"].shape[1]
+    wave = ops.model_outputs_to_waveforms(pred, n_re, n_im, L)
+    assert rel(wave.cpu().numpy(), v["enhanced_wave"]) < 1e-5                        # iSTFT vs the reference's torch.istft
+    alphas = [float(a) for a in v["alphas"]]
+    for tag, w in (("w", torch.from_numpy(z["log.w_mat"])), ("wbig", torch.from_numpy(v["w_big"]))):
+        re, im = ops.crm_directions_to_spectrograms(w.cuda(), n_re[:, 0], n_im[:, 0])
+        assert rel(re.cpu().numpy(), v[f"{tag}_spec_re"]) < 1e-5 and rel(im.cpu().numpy(), v[f"{tag}_spec_im"]) < 1e-5
+        enh, var = ops.pc_direction_waveforms(pred, w.cuda(), alphas, n_re[:, 0], n_im[:, 0], L, 512, 256)
+        assert rel(enh.cpu().numpy(), v["enhanced_wave"]) < 1e-5
+        assert rel(var.cpu().numpy(), v[f"{tag}_waves"]) < 2e-5

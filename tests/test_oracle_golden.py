@@ -202,3 +202,29 @@ def test_mix_with_snr_golden(golden_dir):
         n, c = R.mix_with_snr(torch.from_numpy(z["clean"][i]), torch.from_numpy(z["noise"][i]), float(z["snr"][i]))
         assert np.abs(n.numpy() - z["noisy_out"][i]).max() < 1e-6
         assert np.abs(c.numpy() - z["clean_out"][i]).max() < 1e-6
+
+
+def test_validator_synthesis_golden(golden_dir):
+    """SURVEY row f1 pinned: the oracle's restatement of decompress_cIRM + the TRUE complex product (utils.crm_to_spectogram,
+    utils.py:252-256) + torch.istft reproduces what the reference's own utils.model_outputs_to_waveforms (utils.py:37-72) and
+    the validator's alpha variations (nppc_audio/validator.py:81-101, 244-283) produced (tests/golden/validator_f1.npz,
+    written by make_goldens_validator.py from RUNNING the reference)."""
+    v = np.load(os.path.join(golden_dir, "validator_f1.npz"))
+    z = np.load(os.path.join(golden_dir, "g1_c1.npz"))
+    n_re, n_im = torch.from_numpy(z["noisy_real"][:, 0]), torch.from_numpy(z["noisy_imag"][:, 0])
+    L = z["noisy"].shape[1]
+
+    def spec(m):                                            # compressed cIRM [B,2,F,T] -> true product with the noisy STFT
+        d = R.decompress_mask(m)
+        return d[:, 0] * n_re - d[:, 1] * n_im, d[:, 1] * n_re + d[:, 0] * n_im
+
+    e_re, e_im = spec(torch.from_numpy(z["pred_crm_full"]))
+    assert rel(e_re, v["enhanced_re"]) < 2e-6 and rel(e_im, v["enhanced_im"]) < 2e-6
+    assert rel(R.istft_wave(e_re, e_im, 512, 256, L), v["enhanced_wave"]) < 5e-6
+    for tag, w in (("w", torch.from_numpy(z["log.w_mat"])), ("wbig", torch.from_numpy(v["w_big"]))):
+        for k in range(w.shape[1]):
+            r, i = spec(w[:, k])
+            assert rel(r, v[f"{tag}_spec_re"][:, k]) < 2e-6 and rel(i, v[f"{tag}_spec_im"][:, k]) < 2e-6
+            for ai, a in enumerate(v["alphas"]):
+                got = R.istft_wave(e_re + float(a) * r, e_im + float(a) * i, 512, 256, L)
+                assert rel(got, v[f"{tag}_waves"][:, k, ai]) < 5e-6

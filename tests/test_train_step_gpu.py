@@ -57,6 +57,7 @@ def build_model(c, precision, tmp_path):
 
 
 _FP64_ORACLE = {}
+W_MAT_BF16_TOL = 1.5e-1
 
 
 def bf16_grad_tol(n):
@@ -69,7 +70,7 @@ def bf16_grad_tol(n):
 
 @pytest.mark.parametrize("name,precision", [("g0_tiny", "fp32"), ("g1_c1", "fp32"), ("g2_k5", "fp32"),
                                             ("g2_k5", "bf16"), ("g0_tiny_g1", "fp32")])
-def test_train_step_matches_oracle(name, precision, tmp_path):
+def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
     from nppc_audio.trainer import nppc_base_step
     z, meta = load(name)
     c = meta["config"]
@@ -84,11 +85,13 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
     torch.cuda.synchronize()
 
     # forward quantities against the reference goldens
-    tol = 5e-4 if fp32 else 1.5e-1      # bf16: Gram-Schmidt differences amplify the ~1e-2 bf16 noise of the raw directions
-    assert rel(log["pred_crm"].cpu().numpy(), z["pred_crm"]) < (3e-4 if fp32 else 6e-2)
-    assert rel(log["w_mat"].cpu().numpy(), z["log.w_mat"]) < tol
-    assert abs(float(obj) - meta["objective_at_step"]["500"]) < (2e-5 if fp32 else 2e-2)
-    assert rel(log["reconst_err"].cpu().numpy(), z["log.reconst_err"]) < (1e-4 if fp32 else 5e-2)
+    # (measured values of every run: profiles/r03_parity_errors.json; bf16 limits = 2 x the measured worst)
+    tol = 5e-4 if fp32 else W_MAT_BF16_TOL   # bf16: Gram-Schmidt differences amplify the ~1e-2 bf16 noise of the raw directions
+    # bf16 measured (g2_k5): pred_crm 5.8e-3, w_mat 8.8e-2, objective 3.5e-5, reconst_err 8.6e-5
+    record_err("pred_crm", rel(log["pred_crm"].cpu().numpy(), z["pred_crm"]), 3e-4 if fp32 else 2.5e-2)
+    record_err("w_mat", rel(log["w_mat"].cpu().numpy(), z["log.w_mat"]), tol)
+    record_err("objective_abs", abs(float(obj) - meta["objective_at_step"]["500"]), 2e-5 if fp32 else 1e-3)
+    record_err("reconst_err", rel(log["reconst_err"].cpu().numpy(), z["log.reconst_err"]), 1e-4 if fp32 else 2e-3)
 
     # Every parameter gradient against the oracle's autograd evaluated in FP64.  Why fp64: the reference's own
     # fp32 gradients of the real/imag full-band branches carry up to 1.4e-1 relative error vs fp64 (measured on
@@ -140,6 +143,9 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
             return 0.25 if ill_conditioned(n) else 1e-2
         bad = {n: r for n, r in worst.items() if r > tol_of(n)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
+        record_err("fp32_grad.well_conditioned", max(r for n, r in worst.items() if not ill_conditioned(n)), 1e-2)
+        record_err("fp32_grad.ill_conditioned", max([r for n, r in worst.items() if ill_conditioned(n)] or [0.0]), 0.25)
+        record_err("fp32_grad.cos_deficit", 1.0 - cos, 1e-5)
         assert cos > 0.99999 and abs(np.sqrt(nn_g / nn_r) - 1) < 1e-4
     else:
         # bf16 operands (tolerance table: DESIGN.md section 2): EVERY well-conditioned tensor individually -- sub-band
@@ -153,6 +159,9 @@ def test_train_step_matches_oracle(name, precision, tmp_path):
                  "tcn." + n.rsplit(".", 2)[-2] if ".sequence_model." in n else "fb_fc")
             fam[k] = max(fam.get(k, 0.0), worst[n])
         print(name, "bf16 worst error / max|grad| per well-conditioned family:", {k: f"{v:.2e}" for k, v in sorted(fam.items())})
+        for k, v in fam.items():
+            record_err("bf16_grad." + k, v, bf16_grad_tol("x" + (".prelu" if "prelu" in k else "")))
+        record_err("bf16_grad.cos_deficit", 1.0 - cos, 0.01)
         bad = {n: worst[n] for n in well if worst[n] > bf16_grad_tol(n)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
         assert cos > 0.99 and abs(np.sqrt(nn_g / nn_r) - 1) < 0.05
@@ -329,3 +338,82 @@ def test_pipelined_update_equals_immediate_update(tmp_path):
     moved = max(float((out[True][1][k[len("audio_pc_wrapper."):]].cpu() - v).abs().max()) for k, v in w0.items())
     assert moved > 1e-4                       # three Adam steps of lr 1e-4 really happened
     assert out[True][0][2] < out[True][0][0]
+
+
+def test_model_is_usable_right_after_train_step_without_flush(tmp_path):
+    """The reference lets you call train_step and then use any model freely.  Here train_step ends with the re-pack of the
+    updated weights queued on the engine's side stream (and, in pipeline mode, the whole tail parked): a direct call of the
+    direction net or of the whole model right behind it must wait for that work by itself (FSNEngine.join_side at the top of
+    forward, join_all before the LSTM launches) instead of raising or reading half-written packed weights: outputs equal the
+    ones computed after an explicit flush + synchronise, bit for bit."""
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    z, meta = load("g2_k5")
+    c = meta["config"]
+    model, wts = build_model(c, "bf16", str(tmp_path))
+    cfg = NPPCAudioTrainerConfig(
+        nppc_model_configuration=model.config, data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+        data_loader_configuration=dict(batch_size=c["B"], num_workers=0, pin_memory=False, shuffle=False),
+        optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
+        device="cuda")
+    noisy, clean = (torch.from_numpy(a) for a in waves(z, meta))
+    tr = NPPCAudioTrainer(cfg, dataset=_Mem(noisy, clean))
+    tr.nppc_model.load_state_dict(wts, strict=True)
+    tr.nppc_model.to("cuda")
+    tr.step = 500
+    tr.train_step((noisy.cuda(), clean.cuda()))
+    with torch.no_grad():
+        first = tr.nppc_model(noisy.cuda()).clone()          # no flush, no synchronise in between
+    tr.flush()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        again = tr.nppc_model(noisy.cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(first).all())
+    assert torch.equal(first, again)
+
+
+def test_handoff_timeout_makes_the_update_a_no_op(tmp_path):
+    """A hand-off time-out of a cooperative LSTM kernel leaves wrong numbers in everything computed since; the host only
+    looks at the sticky counters every log interval.  The Adam kernel reads them on the device: with a count planted before
+    a step, that step's update is skipped -- weights and moments bit-identical -- and its objective comes back NaN; the
+    next host check raises.  Clearing the counter lets training continue."""
+    from nppc_audio import ops_lstm
+    from nppc_audio.trainer import NPPCAudioTrainer, NPPCAudioTrainerConfig
+    z, meta = load("g2_k5")
+    c = meta["config"]
+    model, wts = build_model(c, "bf16", str(tmp_path))
+    cfg = NPPCAudioTrainerConfig(
+        nppc_model_configuration=model.config, data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
+        data_loader_configuration=dict(batch_size=c["B"], num_workers=0, pin_memory=False, shuffle=False),
+        optimizer_configuration=dict(type="Adam", args=dict(lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0)),
+        device="cuda")
+    noisy, clean = (torch.from_numpy(a) for a in waves(z, meta))
+    tr = NPPCAudioTrainer(cfg, dataset=_Mem(noisy, clean))
+    tr.nppc_model.load_state_dict(wts, strict=True)
+    tr.nppc_model.to("cuda")
+    tr.step = 500
+    batch = (noisy.cuda(), clean.cuda())
+    ops_lstm.clear_coop_timeouts()
+    _, obj0, _ = tr.train_step(batch)
+    tr.flush()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(obj0))
+    blocks = ops_lstm._flag_blocks()
+    if not blocks:
+        pytest.skip("no cooperative LSTM launch in this configuration")
+    flat = tr.nppc_model.audio_pc_wrapper.net.engine().fp.flat
+    before = flat.detach().clone()
+    m_before = tr._flat_adam.m.clone()
+    blocks[0][-4] = 3                                      # as if three bounded spins had given up during the next step
+    _, obj1, _ = tr.train_step(batch)
+    tr.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(flat.detach(), before) and torch.equal(tr._flat_adam.m, m_before)
+    assert np.isnan(float(obj1))
+    with pytest.raises(RuntimeError, match="hand-off time-out"):
+        tr._check_timeouts("test")
+    assert ops_lstm.coop_timeouts() == 0                   # the check cleared the counter
+    _, obj2, _ = tr.train_step(batch)
+    tr.flush()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(obj2)) and not torch.equal(flat.detach(), before)
