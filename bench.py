@@ -121,37 +121,52 @@ def pmc_traffic(rocprof_pattern, workload):
     return None, "kernel not in the committed PMC summary"
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline():
-    """Reference-shaped CPU path (the oracle restatement, pinned to the reference by tests/golden) on a bounded
-    sample: B=4 x 4 s, K=5, G_pc=2, full train steps (forward x [2 restorer, 3 STFT] + backward + Adam): one warm-up on a
-    0.25 s crop, then 2 timed steps."""
+    """CPU path = the oracle restatement (pinned to the reference by tests/golden) on a bounded sample of the C2 workload:
+    B=8 x 4 s (a quarter of the batch), K=5, G_pc=2, fp32, full train steps (forward + backward + Adam).  Two rows
+    (BASELINE.md section 3): "reference-shaped" (restorer executed twice and the noisy STFT three times per step, exactly as
+    the reference does) -- the `value` -- and "de-duplicated".  One warm-up on a 0.25 s crop, then one timed step per row."""
     sys.path.insert(0, ROOT)
     from oracle import nppc_ref as R
     from oracle import weights as W
     torch.set_num_threads(host_cores())
-    B, L, NT = 4, SECONDS * SR, 2
+    B, L = 8, SECONDS * SR
     spec = W.nppc_spec(K_DIRS)
     P = {k: torch.from_numpy(v) for k, v in W.make_weights(spec, 7).items()}
     train = {k: v.requires_grad_(True) for k, v in P.items() if k.startswith("audio_pc_wrapper")}
     noisy, clean = (torch.from_numpy(a) for a in W.synth_batch(B, L))
     state = {}
 
-    def one(step, n, c):
-        _, obj, _ = R.nppc_step(n, c, P, K_DIRS, step, g_rest=1, g_pc=2, reference_shaped=True)
+    def one(step, n, c, shaped):
+        _, obj, _ = R.nppc_step(n, c, P, K_DIRS, step, g_rest=1, g_pc=2, reference_shaped=shaped)
         names = list(train)
         gs = torch.autograd.grad(obj, [train[k] for k in names])
         with torch.no_grad():
             R.adam_step(train, dict(zip(names, gs)), state, step + 1)
 
-    one(0, noisy[:, :4096], clean[:, :4096])                  # thread-pool / allocator warm-up on a 0.25 s crop
-    t0 = time.perf_counter()
-    for i in range(NT):
-        one(1 + i, noisy, clean)
-    dt = (time.perf_counter() - t0) / NT
+    one(0, noisy[:, :4096], clean[:, :4096], True)            # thread-pool / allocator warm-up on a 0.25 s crop
     frames = B * (1 + L // HOP)
-    return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{NT} train steps, B={B} x {SECONDS} s, K={K_DIRS}, G_pc=2, fp32, reference-shaped "
-                      f"(2x restorer, 3x STFT), {dt:.1f} s/step"}
+    rows = {}
+    for i, (tag, shaped) in enumerate((("reference_shaped", True), ("deduplicated", False))):
+        t0 = time.perf_counter()
+        one(1 + i, noisy, clean, shaped)
+        dt = time.perf_counter() - t0
+        rows[tag] = {"frames_per_s": frames / dt, "s_per_step": dt}
+    return {"value": rows["reference_shaped"]["frames_per_s"], "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "cpu_model": cpu_model(), "rows": rows,
+            "sample": f"1 train step per row after a warm-up, B={B} x {SECONDS} s (a quarter of the C2 batch), K={K_DIRS}, G_pc=2, "
+                      f"fp32; value = reference-shaped row (2x restorer, 3x STFT: {rows['reference_shaped']['s_per_step']:.1f} s/step), "
+                      f"de-duplicated row {rows['deduplicated']['s_per_step']:.1f} s/step"}
 
 
 # ------------------------------------------------------------------------------------------------ algorithmic work
@@ -318,6 +333,12 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
+    dp_info = None
+    if world > 1:        # what the process group really is: the driver can see that RCCL ran with N ranks
+        dp_info = {"world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                   "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                   "gradient_exchange": "bucketed inside backward" if tr._reducer.overlap else "one all-reduce behind backward",
+                   "pipeline_update": bool(tr.pipeline_update)}
     nto = ops_lstm.coop_timeouts()      # sticky counter: covers every launch since the process started
     if nto:      # a bounded hand-off spin gave up: the step's results are wrong, so is any number measured on them
         raise RuntimeError(f"rank {rank}: {nto} cooperative LSTM hand-off time-outs during the run: measurement invalid")
@@ -406,6 +427,8 @@ def main():
         "roofline": roof,
         "lstm_handoff_timeouts": 0,
     }
+    if dp_info is not None:
+        out["dp"] = dp_info
     if world == 1 and a.precision == "bf16" and not a.no_fp32:
         # the reference computes in fp32: the same step in the product's fp32 parity mode (exact-f32 MFMA), outside the
         # timed region.  The bf16 trainer's step-persistent workspaces stay allocated (288 GB of HBM: both fit).

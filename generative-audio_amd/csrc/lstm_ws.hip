@@ -40,12 +40,18 @@ typedef unsigned char lds_u8;   // LDS bytes (the compiler infers the address sp
 constexpr int WS_H = 384, WS_G = 12, WS_UC = 32, WS_KX = 64, WS_MC = 32, WS_NT = 512;
 constexpr int WS_NK1 = (WS_KX + WS_H) / 16;              // 28 k-steps of 16: [x | h1]
 constexpr int WS_NK2 = 2 * WS_H / 16;                    // 48 k-steps: [h1 | h2]
+#ifndef WS_MFMA16
+#define WS_MFMA16 0      // 1: 16x16x32 MFMAs (2 x 2 blocks per wave and k-step) instead of one 32x32x16 per k-step of 16
+#endif
+#if WS_MFMA16
+constexpr int WS_ROWB = (WS_KX + 2 * WS_H) * 2 + 32;     // 1696 bytes per tile row (= 32 mod 64): conflict-free b128 reads of 16 rows x 4 k-groups
+#else
 constexpr int WS_ROWB = (WS_KX + 2 * WS_H) * 2 + 16;     // 1680 bytes per tile row: odd multiple of 16 -> conflict-free b128 reads
+#endif
 constexpr int WS_TILEB = WS_MC * WS_ROWB;                // 53760
 constexpr int WS_OFF_BIAS = 2 * WS_TILEB;                // [2 layers][32 units][4 gates (i,g,f,o)] fp32
-constexpr int WS_OFF_WH = WS_OFF_BIAS + 2 * WS_UC * 16;  // head weights as 16x16x32 A fragments [12 kk][64 lanes][8] bf16
-constexpr int WS_NKL = 4;                                // layer-2 k-steps whose A fragments stay in LDS (register budget)
-constexpr int WS_OFF_W2L = WS_OFF_WH + 12 * 64 * 16;     // [4 ug][WS_NKL][64 lanes][8] bf16
+constexpr int WS_NKL = 4;                                // layer-2 A fragments (16 k each) that stay in LDS (register budget)
+constexpr int WS_OFF_W2L = WS_OFF_BIAS + 2 * WS_UC * 16; // [4 ug][WS_NKL][64 lanes][8] bf16
 constexpr int WS_OFF_CNT = WS_OFF_W2L + 4 * WS_NKL * 1024; // readers-done counter of the output staging (training), 16 bytes
 constexpr int WS_OFF_STG = WS_OFF_CNT + 16;              // output staging [2 layers][32 seq][STROW] (inference: x 2 item parities)
 constexpr int WS_STROW_INF = 64 + 16;                    // inference: the CU's 32 units of h (64 B) + pad
@@ -128,7 +134,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base, long
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, valid ? (unsigned)(N * row_bytes) : 0u, 0x00020000);
 }
 
-// cell update of one layer for this lane's 4 units x 1 sequence.  acc[4m + g]: unit m, gate g in (i, g, f, o).
+// cell update of one layer for this lane's 4 cells.  acc[4m + g]: cell m, gate g in (i, g, f, o).  32x32 MFMA: cell m = unit
+// 4 hh + m of sequence lane & 31; 16x16 MFMAs: cell m = 2 sb + rb = unit 2 q + rb of sequence 16 sb + (lane & 15).  Either
+// way cells 2k, 2k + 1 are neighbouring units of one sequence: hpk[k] / gpk[k] / cpk[k] pack those pairs.
 template <bool TRAIN>
 __device__ __forceinline__ void ws_cell(const f32x16& acc, f32x4& c, unsigned (&hpk)[2], u32x4 (&gpk)[2], unsigned (&cpk)[2]) {
   float hv[4];
@@ -186,11 +194,23 @@ __device__ __forceinline__ void ws_stage_out(unsigned char* smem, int layer, int
   constexpr int STROW = TRAIN ? WS_STROW_TRN : WS_STROW_INF;
   constexpr int HOFF = TRAIN ? 320 : 0;
   asm volatile("" : "+v"(lane));        // re-derive the addresses below per item: hoisted, they would live in VGPRs across the GEMMs
-  const int seq = lane & 31, hh = lane >> 5;
   if (TRAIN) {
     volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + WS_OFF_CNT);
     for (unsigned spins = 0; *cnt < 4u * (unsigned)(i + 1) && spins < (1u << 20); ++spins) {}   // generation i - 1 has been read
   }
+#if WS_MFMA16
+  const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {      // cells 2 sb, 2 sb + 1: units 2 q, 2 q + 1 of sequence 16 sb + n
+    unsigned char* wrow = ws_stg<TRAIN>(smem, layer, i & 1) + (16 * sb + n) * STROW;
+    if (TRAIN) {
+      *reinterpret_cast<u32x4*>(wrow + ug * 64 + q * 16) = gpk[sb];
+      *reinterpret_cast<unsigned*>(wrow + 256 + ug * 16 + q * 4) = cpk[sb];
+    }
+    *reinterpret_cast<unsigned*>(wrow + HOFF + ug * 16 + q * 4) = hpk[sb];
+  }
+#else
+  const int seq = lane & 31, hh = lane >> 5;
   unsigned char* wrow = ws_stg<TRAIN>(smem, layer, i & 1) + seq * STROW;
   if (TRAIN) {
     *reinterpret_cast<u32x4*>(wrow + ug * 64 + hh * 32) = gpk[0];
@@ -198,6 +218,7 @@ __device__ __forceinline__ void ws_stage_out(unsigned char* smem, int layer, int
     *reinterpret_cast<u32x2*>(wrow + 256 + ug * 16 + hh * 8) = u32x2{cpk[0], cpk[1]};
   }
   *reinterpret_cast<u32x2*>(wrow + HOFF + ug * 16 + hh * 8) = u32x2{hpk[0], hpk[1]};
+#endif
 }
 // flush of staging generation g (iteration g): layer-2 outputs of item g, layer-1 outputs of item g - 1 (layer 1 runs its
 // cell update one iteration late, see the kernel).  Done by the four layer-2 waves, wave ug rows [8 ug, 8 ug + 8) of both
@@ -240,6 +261,21 @@ __device__ __forceinline__ void ws_flush_store(const WsFlush& f, int layer, int 
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const lds_u8* p) { return *reinterpret_cast<const bf16x8*>(p); }
+#if WS_MFMA16
+// one k-step of 32 on the 2 x 2 blocks of 16x16: a[rb] = weights (gate rows 16 rb ..), b[sb] = activations (sequences 16 sb ..);
+// accumulator element block m = 2 sb + rb (see ws_cell)
+__device__ __forceinline__ void ws_mfma16x4(f32x16& acc, const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1) {
+  f32x4 c[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) c[m] = f32x4{acc[4 * m], acc[4 * m + 1], acc[4 * m + 2], acc[4 * m + 3]};
+  c[0] = mma16(a0, b0, c[0]);
+  c[1] = mma16(a1, b0, c[1]);
+  c[2] = mma16(a0, b1, c[2]);
+  c[3] = mma16(a1, b1, c[3]);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { acc[4 * m] = c[m][0]; acc[4 * m + 1] = c[m][1]; acc[4 * m + 2] = c[m][2]; acc[4 * m + 3] = c[m][3]; }
+}
+#endif
 #ifdef WS_DIAG_NOMFMA
 // diagnostic build: the matrix pipe is not used (one VALU instruction keeps the operands alive)
 __device__ __forceinline__ f32x16 ws_mfma(const bf16x8& a, const bf16x8& b, f32x16 c) {
@@ -278,25 +314,45 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       bl[e] = (l ? a.bias2 : a.bias1)[tg * WS_H + cu * WS_UC + u];
     }
     if (tid < 4) reinterpret_cast<unsigned*>(smem + WS_OFF_CNT)[tid] = 0u;
-    if (a.whp) {
-      const bf16_t* wh = reinterpret_cast<const bf16_t*>(a.whp);
-      for (int e = tid; e < 12 * 64; e += WS_NT) {
-        const int kk = e >> 6, l = e & 63;
-        *reinterpret_cast<u32x4*>(smem + WS_OFF_WH + e * 16) =
-            *reinterpret_cast<const u32x4*>(wh + (size_t)(l & 15) * WS_H + 32 * kk + 8 * (l >> 4));
-      }
-    }
   }
   gu32* flags = (gu32*)(a.flags + (size_t)cluster * a.nch_max * 16);
   gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * a.nch_max * 16);
   const lds_u8* ltile = reinterpret_cast<const lds_u8*>(smem);
   // B fragment (activations) of this lane: row seq, k = 8 hh + j of each 16-wide k-step
+#if WS_MFMA16
+  // 16x16x32: lane (n = lane & 15, q = lane >> 4) reads row 16 sb + n, k = 32 kk + 8 q + j
+  const int boff = (lane & 15) * WS_ROWB + (lane >> 4) * 16 + (layer ? WS_KX * 2 : 0);
+  const int bias_unit = ug * 8 + 2 * (lane >> 4);                       // cells 2 sb + rb: unit 2 q + rb
+#else
   const int boff = seq * WS_ROWB + hh * 16 + (layer ? WS_KX * 2 : 0);
+#endif
   // fp32 cell state of (chunk, layer, unit group): 16 bytes per lane, private to this wave (plain accesses, L2-resident);
   // addressed through a descriptor: scalar chunk offset + the lane offset, no 64-bit pointer per lane
   const __amdgpu_buffer_rsrc_t cstr = __builtin_amdgcn_make_buffer_rsrc(
       a.cst + (((size_t)cluster * WS_G + cu) * a.nch_max * 2 + layer) * 4 * 256 + ug * 256, 0, (unsigned)a.nch_max * 2 * 4 * 256 * 4, 0x00020000);
 
+  // accumulators start from the biases of the lane's cells (LDS: [layer][32 units][i,g,f,o])
+  auto bias_init = [&](f32x16& acc, int l) {
+#if WS_MFMA16
+    const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (l * WS_UC + bias_unit) * 16;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + rb * 16);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const int m = 2 * sb + rb;
+        acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+      }
+    }
+#else
+    const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (l * WS_UC + ug * 8 + 4 * hh) * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
+      acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
+    }
+#endif
+  };
   auto mk_item = [&](int s_, int c_) {
     WsItem it;                                                     // readfirstlane: provably wave-uniform (SGPRs, no waterfall
     it.s = __builtin_amdgcn_readfirstlane(s_);                     // loops around the buffer accesses that take them as offsets)
@@ -437,11 +493,11 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       if (a.whp && ug >= 2 && it.s >= 2 && (it.c + it.s) % WS_G == cu) {
         const int n16 = lane & 15, q = lane >> 4, half = ug - 2;
         const lds_u8* bp = ltile + buf * WS_TILEB + (16 * half + n16) * WS_ROWB + (WS_KX + WS_H) * 2 + q * 16;
-        const lds_u8* ap = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_WH + lane * 16;
+        const bf16_t* ap = reinterpret_cast<const bf16_t*>(a.whp) + (size_t)n16 * WS_H + 8 * q;   // A fragments: L2-resident, 12 KB
         f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 12; ++kk)
-          hacc = mma16(*reinterpret_cast<const bf16x8*>(ap + kk * 1024), *reinterpret_cast<const bf16x8*>(bp + kk * 64), hacc);
+          hacc = mma16(*reinterpret_cast<const bf16x8*>(ap + kk * 32), *reinterpret_cast<const bf16x8*>(bp + kk * 64), hacc);
         float* hp = a.hpart + ((size_t)(it.s - 2) * N + it.row0 + 16 * half + n16) * a.O;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -454,16 +510,27 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       WST(1)
       {
         // ---- layer 1 of time s: gates = W1 . [x_s | h1_{s-1}]^T + b
-        {
-          const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (ug * 8 + 4 * hh) * 16;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
-            acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
-          }
-        }
+        bias_init(acc, 0);
         const lds_u8* bp = ltile + buf * WS_TILEB + boff;
         bf16x8 b[WS_PF];
+#if WS_MFMA16
+        // B fragment e = 2 kk + sb: rows 16 sb .., k-step kk of 32; A fragments w[2 kk + rb]
+        auto rdb = [&](int e) { return lds_frag(bp + (e & 1) * 16 * WS_ROWB + (e >> 1) * 64); };
+#pragma unroll
+        for (int e = 0; e < WS_PF; ++e) b[e] = rdb(e);
+#pragma unroll
+        for (int kk = 0; kk < WS_NK1 / 2; ++kk) {
+          ws_mfma16x4(acc, w[2 * kk], w[2 * kk + 1], b[(2 * kk) % WS_PF], b[(2 * kk + 1) % WS_PF]);
+          if (2 * kk + WS_PF < WS_NK1) b[(2 * kk) % WS_PF] = rdb(2 * kk + WS_PF);
+          if (2 * kk + 1 + WS_PF < WS_NK1) b[(2 * kk + 1) % WS_PF] = rdb(2 * kk + 1 + WS_PF);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + WS_PF, 0);
+#pragma unroll
+        for (int kk = 0; kk < WS_NK1 / 2; ++kk) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#else
 #pragma unroll
         for (int d = 0; d < WS_PF; ++d) b[d] = lds_frag(bp + d * 32);
 #pragma unroll
@@ -479,6 +546,7 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       WST(2)
@@ -544,20 +612,50 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       WST(0)
       // ---- layer 2 of time s - 1: gates = W2 . [h1_{s-1} | h2_{s-2}]^T + b (every item: see layer 1)
       f32x16 acc;
-      {
-        const lds_u8* bl = reinterpret_cast<const lds_u8*>(smem) + WS_OFF_BIAS + (WS_UC + ug * 8 + 4 * hh) * 16;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bl + m * 16);
-          acc[4 * m] = b[0]; acc[4 * m + 1] = b[1]; acc[4 * m + 2] = b[2]; acc[4 * m + 3] = b[3];
-        }
-      }
+      bias_init(acc, 1);
       {
         // one ring of WS_PF LDS reads in flight feeds the MFMAs: operand stream W_0 B_0 .. W_{NKL-1} B_{NKL-1} B_NKL .. B_47
         // (the first NKL k-steps take their A fragment from LDS as well: 176 + 16 + 24 registers at the peak)
         const lds_u8* bp = ltile + buf * WS_TILEB + boff;
         constexpr int E = WS_NK2 + WS_NKL;
         bf16x8 r[WS_PF];
+#if WS_MFMA16
+        // operand stream: k-steps 0, 1 (of 32): W(kk,0) W(kk,1) B(kk,0) B(kk,1); then B(kk,0) B(kk,1); W2L holds fragments
+        // 2 kk + rb of the first two k-steps, registers w[2 kk + rb - WS_NKL] the rest
+        auto rd = [&](int e) {
+          if (e < 2 * WS_NKL) {
+            const int kk = e >> 2, j = e & 3;
+            return j < 2 ? lds_frag(wl + (2 * kk + j) * 1024) : lds_frag(bp + (j & 1) * 16 * WS_ROWB + kk * 64);
+          }
+          const int f = e - WS_NKL;                                  // B fragment index 2 kk + sb
+          return lds_frag(bp + (f & 1) * 16 * WS_ROWB + (f >> 1) * 64);
+        };
+#pragma unroll
+        for (int e = 0; e < WS_PF; ++e) r[e] = rd(e);
+#pragma unroll
+        for (int kk = 0; kk < WS_NK2 / 2; ++kk) {
+          if (2 * kk < WS_NKL) {
+            const int e = 4 * kk;
+            ws_mfma16x4(acc, r[e % WS_PF], r[(e + 1) % WS_PF], r[(e + 2) % WS_PF], r[(e + 3) % WS_PF]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              if (e + d + WS_PF < E) r[(e + d) % WS_PF] = rd(e + d + WS_PF);
+          } else {
+            const int e = WS_NKL + 2 * kk;
+            ws_mfma16x4(acc, w[2 * kk - WS_NKL], w[2 * kk + 1 - WS_NKL], r[e % WS_PF], r[(e + 1) % WS_PF]);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+              if (e + d + WS_PF < E) r[(e + d) % WS_PF] = rd(e + d + WS_PF);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + WS_PF, 0);
+#pragma unroll
+        for (int kk = 0; kk < WS_NK2 / 2; ++kk) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          if (2 * kk < WS_NKL) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#else
         auto rd = [&](int e) {
           if (e < 2 * WS_NKL) return (e & 1) ? lds_frag(bp + (e >> 1) * 32) : lds_frag(wl + (e >> 1) * 1024);
           return lds_frag(bp + (e - WS_NKL) * 32);
@@ -584,6 +682,7 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
           if (ks < WS_NKL) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+#endif
       }
       WST(1)
       if (polls) {
@@ -648,11 +747,18 @@ __global__ void lstm_ws_pack_kernel(const float* __restrict__ w_ih, const float*
     const int ks = f % nk; f /= nk;
     const int ug = f & 3;
     const int cu = (int)(f >> 2);
+    const int tgmap[4] = {0, 2, 1, 3};
+#if WS_MFMA16
+    // fragment ks = 2 kk + rb: A operand of the 16x16x32 MFMA, row r16 = l & 15 = 4 q' + gate -> unit 2 q' + rb
+    const int kk = ks >> 1, rb = ks & 1, r16 = l & 15;
+    const int ul = 2 * (r16 >> 2) + rb, g = r16 & 3;
+    const int k = 32 * kk + 8 * (l >> 4) + j;
+#else
     const int r = l & 31, g = r & 3, ui = r >> 2;
     const int ul = 4 * (ui & 1) + (ui >> 1);
-    const int tg = g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 1 : 3));
-    const int row = tg * WS_H + cu * WS_UC + ug * 8 + ul;
     const int k = 16 * ks + 8 * (l >> 5) + j;
+#endif
+    const int row = tgmap[g] * WS_H + cu * WS_UC + ug * 8 + ul;
     float v;
     if (layer == 1) v = k < WS_KX ? (k < I ? w_ih[(size_t)row * I + k] : 0.f) : w_hh[(size_t)row * WS_H + (k - WS_KX)];
     else v = k < WS_H ? w_ih[(size_t)row * WS_H + k] : w_hh[(size_t)row * WS_H + (k - WS_H)];

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnppc_hip.so")
+LIB_PATH = os.environ.get("NPPC_HIP_LIB") or os.path.join(_HERE, "libnppc_hip.so")   # (NPPC_HIP_LIB: diagnostic builds, tools/diag)
 
 PREC_BF16 = 0
 PREC_F32 = 1

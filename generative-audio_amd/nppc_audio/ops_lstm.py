@@ -65,7 +65,13 @@ def pick_mtile(n_seq, prec, train, n_cu=256):
 
 _WS = {}
 COOP = True          # use the cooperative (weights split over CU pairs) kernels when the shape allows it
-WS = os.environ.get("NPPC_LSTM_WS", "1") != "0"    # weight-stationary 12-CU clusters for the forward when the plan allows
+# weight-stationary 12-CU clusters (csrc/lstm_ws.hip) for the forward when the plan allows: "0" never (default), "1" inference
+# launches, "2" also the training forward.  Measured at C2 (profiles/r03_lstm_ws_variants.txt, r03_bench_ws_modes.txt): ALONE
+# the restorer launch takes 8.9 ms against 9.8 ms for the CU-pair kernel and the no-grad direction launch 4.4 against 5.6,
+# but INSIDE the train step the same launches are slower (9.3 vs 9.1 ms) and so are the launches behind them: these kernels
+# are bound by what the chip may draw, and the cluster kernel's hidden-state gather (4.3 TB/s from L2) costs 20 % of its clock
+WS_MODE = os.environ.get("NPPC_LSTM_WS", "0")
+WS = WS_MODE != "0"
 N_CU = None
 
 
@@ -199,7 +205,7 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
-    if mtile == "ws" or (WS and COOP and mtile is None):
+    if mtile == "ws" or (WS and COOP and mtile is None and (not train or WS_MODE == "2")):
         ws_out = _lstm2_forward_ws(x_tm, packed, train, head, out, tag)
         if ws_out is not None:
             return ws_out

@@ -5,12 +5,15 @@ time of an item goes.  Diagnostic builds give garbage results (and may count tim
 import glob, os, subprocess, sys
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 VARIANTS = {"base": [], "nocell": ["-DWS_DIAG_NOCELL"], "notilewrite": ["-DWS_DIAG_NOTILEWRITE"], "nogather": ["-DWS_DIAG_NOGATHER"],
-            "gather_l2": ["-DWS_DIAG_GATHERL2"],
+            "gather_l2": ["-DWS_DIAG_GATHERL2"], "mfma16": ["-DWS_MFMA16=1"], "mfma16_all_but_mfma": ["-DWS_MFMA16=1", "-DWS_DIAG_NOGATHER", "-DWS_DIAG_NOTILEWRITE", "-DWS_DIAG_NOFLUSH", "-DWS_DIAG_NOCELL"],
             "noflush": ["-DWS_DIAG_NOFLUSH"], "nomfma": ["-DWS_DIAG_NOMFMA"], "nobarrier": ["-DWS_DIAG_NOBARRIER"],
             "nogather_notilewrite_noflush": ["-DWS_DIAG_NOGATHER", "-DWS_DIAG_NOTILEWRITE", "-DWS_DIAG_NOFLUSH"],
             "all_but_mfma": ["-DWS_DIAG_NOGATHER", "-DWS_DIAG_NOTILEWRITE", "-DWS_DIAG_NOFLUSH", "-DWS_DIAG_NOCELL"]}
 so = lambda n: os.path.join(root, "tools", "diag", f"libws_{n}.so")
 if "--build" in sys.argv:
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if only:
+        VARIANTS = {k: v for k, v in VARIANTS.items() if k in only}
     csrc = os.path.join(root, "generative-audio_amd", "csrc")
     objs = [os.path.join(root, "generative-audio_amd", "build", os.path.basename(f)[:-4] + ".o") for f in sorted(glob.glob(csrc + "/*.hip"))
             if not f.endswith("lstm_ws.hip")]
