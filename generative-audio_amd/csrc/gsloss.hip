@@ -101,6 +101,95 @@ __global__ __launch_bounds__(256) void gram_kernel(VecSet A, VecSet Bs, double* 
   }
 }
 
+// four consecutive t per lane (16-byte loads; N % 4 == 0, 16-byte aligned vectors)
+template <int KV>
+__device__ __forceinline__ void load_set4(const VecSet& s, int K, int b, long N, long t, float4 (&re)[KV], float4 (&im)[KV]) {
+#pragma unroll
+  for (int i = 0; i < KV; ++i) {
+    if (i < K) {
+      const float* p = s.v + ((size_t)(b * K + i) * 2) * N + t;
+      re[i] = *reinterpret_cast<const float4*>(p);
+      im[i] = *reinterpret_cast<const float4*>(p + N);
+    } else if (s.gt) {
+      const float* g = s.gt + (size_t)b * 2 * N + t;
+      const float* q = s.pred + (size_t)b * 2 * N + t;
+      const float4 g0 = *reinterpret_cast<const float4*>(g), q0 = *reinterpret_cast<const float4*>(q);
+      const float4 g1 = *reinterpret_cast<const float4*>(g + N), q1 = *reinterpret_cast<const float4*>(q + N);
+      re[i] = make_float4(g0.x - q0.x, g0.y - q0.y, g0.z - q0.z, g0.w - q0.w);
+      im[i] = make_float4(g1.x - q1.x, g1.y - q1.y, g1.z - q1.z, g1.w - q1.w);
+    } else {
+      re[i] = im[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+__device__ __forceinline__ float f4(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// the same Gram matrix with 16-byte loads: every lane owns four consecutive t per iteration and keeps 2 x KV (SAME) or 4 x KV
+// such loads in flight -- the scalar kernel had a dozen 4-byte loads per lane in flight on 256 workgroups and ran at 1 TB/s.
+// Products and sums stay fp64 (fp32 x fp32 is exact in fp64): 84 fp64 FMAs per t at KV = 6 are a few microseconds chip-wide,
+// the kernel is bound by its memory-level parallelism, not by the arithmetic.
+template <int KV, bool SAME>
+__global__ __launch_bounds__(256) void gram4_kernel(VecSet A, VecSet Bs, double* __restrict__ out, int K, long N, long chunk) {
+  constexpr int NP = SAME ? KV * (KV + 1) / 2 : KV * KV;
+  __shared__ double red[4][NP * 2];
+  const int b = blockIdx.y;
+  const long t0 = (long)blockIdx.x * chunk;
+  const long t1 = t0 + chunk < N ? t0 + chunk : N;
+  double ar[NP], ai[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) ar[i] = ai[i] = 0.0;
+  for (long t = t0 + 4 * threadIdx.x; t < t1; t += 1024) {
+    float4 xr[KV], xi[KV], yr[KV], yi[KV];
+    load_set4<KV>(A, K, b, N, t, xr, xi);
+    if (!SAME) load_set4<KV>(Bs, K, b, N, t, yr, yi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int p = 0;
+#pragma unroll
+      for (int i = 0; i < KV; ++i)
+#pragma unroll
+        for (int n = SAME ? i : 0; n < KV; ++n) {
+          const double a_r = f4(xr[i], e), a_i = f4(xi[i], e);
+          const double b_r = SAME ? f4(xr[n], e) : f4(yr[n], e), b_i = SAME ? f4(xi[n], e) : f4(yi[n], e);
+          ar[p] += a_r * b_r + a_i * b_i;
+          ai[p] += a_r * b_i - a_i * b_r;
+          ++p;
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double r = wave_sum(ar[i]), m = wave_sum(ai[i]);
+    if (lane == 0) { red[wave][2 * i] = r; red[wave][2 * i + 1] = m; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int p = threadIdx.x;
+    const double r = red[0][2 * p] + red[1][2 * p] + red[2][2 * p] + red[3][2 * p];
+    const double m = red[0][2 * p + 1] + red[1][2 * p + 1] + red[2][2 * p + 1] + red[3][2 * p + 1];
+    int i = 0, n = p;
+    if (SAME) {
+      int rem = p;
+      for (i = 0; i < KV; ++i) {
+        if (rem < KV - i) break;
+        rem -= KV - i;
+      }
+      n = i + rem;
+    } else {
+      i = p / KV;
+      n = p % KV;
+    }
+    double* o = out + (size_t)b * KV * KV * 2;
+    atomicAdd(o + (i * KV + n) * 2, r);
+    atomicAdd(o + (i * KV + n) * 2 + 1, m);
+    if (SAME && n != i) {
+      atomicAdd(o + (n * KV + i) * 2, r);
+      atomicAdd(o + (n * KV + i) * 2 + 1, -m);
+    }
+  }
+}
+
 // out_i[t] = sum_m M1[i][m] * A_m[t] + sum_m M2[i][m] * B_m[t]      (complex coefficients, i,m < K; set index K of
 // A = gt - pred when present).  M1/M2: [B][KV][KV] double2, null = skip.  out [B][K][2][N].  fp64 combination.
 template <int KV>
@@ -138,6 +227,52 @@ __global__ __launch_bounds__(256) void combine_kernel(VecSet A, const double* __
       float* p = out + ((size_t)(b * K + i) * 2) * N + t;
       p[0] = (float)orr;
       p[N] = (float)oi;
+    }
+  }
+}
+
+// the same combination, four consecutive t per lane (16-byte loads and stores)
+template <int KV>
+__global__ __launch_bounds__(256) void combine4_kernel(VecSet A, const double* __restrict__ M1, VecSet Bs,
+                                                       const double* __restrict__ M2, float* __restrict__ out, int K, long N) {
+  __shared__ double2 c1[KV * KV], c2[KV * KV];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < KV * KV; i += 256) {
+    c1[i] = M1 ? make_double2(M1[((size_t)b * KV * KV + i) * 2], M1[((size_t)b * KV * KV + i) * 2 + 1]) : make_double2(0, 0);
+    c2[i] = M2 ? make_double2(M2[((size_t)b * KV * KV + i) * 2], M2[((size_t)b * KV * KV + i) * 2 + 1]) : make_double2(0, 0);
+  }
+  __syncthreads();
+  for (long t = ((long)blockIdx.x * 256 + threadIdx.x) * 4; t < N; t += (long)gridDim.x * 1024) {
+    float4 xr[KV], xi[KV], yr[KV], yi[KV];
+    load_set4<KV>(A, K, b, N, t, xr, xi);
+    if (M2) load_set4<KV>(Bs, K, b, N, t, yr, yi);
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      if (i >= K) break;
+      float o_r[4], o_i[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double orr = 0.0, oi = 0.0;
+#pragma unroll
+        for (int m = 0; m < KV; ++m) {
+          const double2 c = c1[i * KV + m];
+          orr += c.x * f4(xr[m], e) - c.y * f4(xi[m], e);
+          oi += c.x * f4(xi[m], e) + c.y * f4(xr[m], e);
+        }
+        if (M2) {
+#pragma unroll
+          for (int m = 0; m < KV; ++m) {
+            const double2 c = c2[i * KV + m];
+            orr += c.x * f4(yr[m], e) - c.y * f4(yi[m], e);
+            oi += c.x * f4(yi[m], e) + c.y * f4(yr[m], e);
+          }
+        }
+        o_r[e] = (float)orr;
+        o_i[e] = (float)oi;
+      }
+      float* p = out + ((size_t)(b * K + i) * 2) * N + t;
+      *reinterpret_cast<float4*>(p) = make_float4(o_r[0], o_r[1], o_r[2], o_r[3]);
+      *reinterpret_cast<float4*>(p + N) = make_float4(o_i[0], o_i[1], o_i[2], o_i[3]);
     }
   }
 }
@@ -375,6 +510,16 @@ __global__ void loss_bwd_coef_kernel(const double* __restrict__ coefA, const dou
 
 template <int KV>
 static void launch_gram(const VecSet& A, const VecSet& Bs, int same, double* out, int B, int K, long N, hipStream_t s) {
+  auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (N % 4 == 0 && al16(A.v) && al16(A.gt) && al16(A.pred) && al16(Bs.v) && (same || KV <= 7)) {   // (KV > 7, two sets: registers)
+    const long chunk4 = 1024L * 2;                     // two iterations of 4 t per lane: 512 workgroups at C2
+    dim3 grid4(ceil_div(N, chunk4), B);
+    if (same)
+      hipLaunchKernelGGL((gram4_kernel<KV, true>), grid4, dim3(256), 0, s, A, Bs, out, K, N, chunk4);
+    else
+      hipLaunchKernelGGL((gram4_kernel<KV, false>), grid4, dim3(256), 0, s, A, Bs, out, K, N, chunk4);
+    return;
+  }
   const long chunk = 256L * 16;
   dim3 grid(ceil_div(N, chunk), B);
   if (same)
@@ -385,6 +530,13 @@ static void launch_gram(const VecSet& A, const VecSet& Bs, int same, double* out
 template <int KV>
 static void launch_combine(const VecSet& A, const double* M1, const VecSet& Bs, const double* M2, float* out, int B, int K,
                            long N, hipStream_t s) {
+  auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (N % 4 == 0 && al16(A.v) && al16(A.gt) && al16(A.pred) && al16(Bs.v) && al16(out)) {
+    long g4 = (N / 4 + 255) / 256;
+    if (g4 > 64) g4 = 64;
+    hipLaunchKernelGGL(combine4_kernel<KV>, dim3((int)g4, B), dim3(256), 0, s, A, M1, Bs, M2, out, K, N);
+    return;
+  }
   long g = (N + 255) / 256;
   if (g > 256) g = 256;
   hipLaunchKernelGGL(combine_kernel<KV>, dim3((int)g, B), dim3(256), 0, s, A, M1, Bs, M2, out, K, N);
