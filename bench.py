@@ -42,8 +42,8 @@ NFFT, HOP, NF = 512, 256, 257
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3       # fp32 matrix (= vector) peak
 PEAK_HBM_GBS = 8000.0
-PMC_CSV = os.path.join(ROOT, "profiles", "r02_bench_c2_bf16_pmc_traffic.csv")
-PMC_STAMP = os.path.join(ROOT, "profiles", "r02_bench_c2_bf16_pmc_stamp.json")
+PMC_CSV = os.path.join(ROOT, "profiles", "r03_bench_c2_bf16_pmc_traffic.csv")
+PMC_STAMP = os.path.join(ROOT, "profiles", "r03_bench_c2_bf16_pmc_stamp.json")
 
 
 def build_trainer(precision, rank, world, batch, length, n_dirs=K_DIRS):
@@ -90,34 +90,43 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def kernel_source_hash():
-    """identifies the kernel sources of the running tree (the GPU box has no .git): sha256 over csrc + the C header"""
+def kernel_source_hash(files=None):
+    """identifies the kernel sources of the running tree (the GPU box has no .git): sha256 over csrc + the C header, or
+    over the listed files of csrc (the translation unit of one kernel: a PMC stamp names the files it covers)"""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "generative-audio_amd", "csrc")
-    for f in sorted(os.listdir(csrc)) + ["../../include/nppc_hip.h"]:
+    for f in (sorted(os.listdir(csrc)) if files is None else sorted(files)) + ["../../include/nppc_hip.h"]:
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(rocprof_pattern, workload):
+def pmc_traffic(rocprof_pattern, workload, PMC_CSV=None, PMC_STAMP=None, expect="C2", aggregate=False):
     """HBM bytes per launch of a kernel (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) from the committed rocprofv3
     counter passes of this same command (tools/summarize_pmc.py; counters cannot be collected from inside the timed
     process).  The passes are stamped with the hash of the kernel sources they profiled: a different running tree, a
     different workload or a missing file gives null."""
     import csv
-    if workload != "C2" or rocprof_pattern is None or not (os.path.exists(PMC_CSV) and os.path.exists(PMC_STAMP)):
+    PMC_CSV, PMC_STAMP = PMC_CSV or globals()["PMC_CSV"], PMC_STAMP or globals()["PMC_STAMP"]
+    if workload != expect or rocprof_pattern is None or not (os.path.exists(PMC_CSV) and os.path.exists(PMC_STAMP)):
         return None, "no committed PMC pass for this kernel / configuration"
     stamp = json.load(open(PMC_STAMP))
-    if stamp.get("kernel_source_hash") != kernel_source_hash():
+    now = kernel_source_hash(stamp.get("files"))
+    if stamp.get("kernel_source_hash") != now:
         return None, (f"committed PMC pass profiled kernel sources {stamp.get('kernel_source_hash')} (git {stamp.get('git_head')}), "
-                      f"the running tree is {kernel_source_hash()}: stale, not reported")
+                      f"the running tree is {now}: stale, not reported")
+    note = (f"bytes per launch, {os.path.relpath(PMC_CSV, ROOT)} (separate --pmc passes, git {stamp.get('git_head')}, "
+            f"kernel sources {stamp.get('kernel_source_hash')})")
+    tot, n = 0.0, 0
     with open(PMC_CSV) as f:
         for r in csv.DictReader(f):
             if rocprof_pattern in r["kernel"]:
                 mb = float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])
-                return mb * 1048576.0, (f"bytes per launch, {os.path.relpath(PMC_CSV, ROOT)} (separate --pmc passes, git "
-                                        f"{stamp.get('git_head')}, kernel sources {stamp.get('kernel_source_hash')})")
+                if not aggregate:
+                    return mb * 1048576.0, note
+                tot, n = tot + mb * 1048576.0 * int(r["launches"]), n + int(r["launches"])
+    if n:           # a family served by several template instantiations of one kernel: launch-weighted mean
+        return tot / n, note + f"; mean over the {n} profiled launches of every '{rocprof_pattern}' instantiation"
     return None, "kernel not in the committed PMC summary"
 
 

@@ -22,6 +22,10 @@ sys.path.insert(0, os.path.join(ROOT, "generative-audio_amd"))
 sys.path.insert(0, ROOT)
 NFFT, HOP, K_DIRS = 255, 128, 5
 PEAK = {"bf16": 2500.0, "fp32": 157.3}
+# rocprofv3 kernel name of each HIP-event family (unet_engine.PROFILE kinds) and the committed counter passes of this command
+ROCPROF_NAME = {"conv_fwd": "conv_tiled_kernel", "conv_bwd_data": "conv_tiled_kernel", "conv_wgrad": "gemm_tn_tiled_kernel"}
+PMC_CSV = os.path.join(ROOT, "profiles", "r03_bench_c3_bf16_pmc_traffic.csv")
+PMC_STAMP = os.path.join(ROOT, "profiles", "r03_bench_c3_bf16_pmc_stamp.json")
 
 
 def log(msg):
@@ -138,6 +142,11 @@ def main(argv=None):
             for k, v in agg.items()}
     dom_name, dom = max(kern.items(), key=lambda kv: kv[1]["ms_per_step"])
     frames = a.batch * T
+    ms_step = 1e3 * dt / a.steps
+    flops_step = sum(v[0] for v in agg.values()) / a.steps
+    import bench
+    wl = "C3" if (a.batch, a.seconds, a.precision) == (32, 4.0, "bf16") else "custom"
+    traffic, traffic_note = bench.pmc_traffic(ROCPROF_NAME.get(dom_name), wl, PMC_CSV, PMC_STAMP, expect="C3", aggregate=True)
     out = {
         "metric": "spectrogram-frames/sec, inpainting NPPC K=5 U-Net train step",
         "value": frames * a.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
@@ -147,7 +156,11 @@ def main(argv=None):
                                f"{a.seconds:g}s@16kHz, STFT {NFFT}/{HOP} (F={F}, T={T}), full train step "
                                f"(fwd+loss+bwd+clip+Adam)", "frames_per_step": frames, "objective_last": float(objective)},
         "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": dom["tflops"], "peak": PEAK[a.precision],
-                     "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK[a.precision], "traffic": None, "conv_families": kern},
+                     "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK[a.precision], "traffic": traffic,
+                     "traffic_note": traffic_note, "conv_families": kern,
+                     "step": {"algorithmic_flop": flops_step, "achieved": flops_step / (ms_step * 1e-3) / 1e12,
+                              "frac": flops_step / (ms_step * 1e-3) / 1e12 / PEAK[a.precision],
+                              "note": "convolution FLOPs only (2*MACs of every conv launch of the step) / whole-step time"}},
     }
     log(f"timed region done: {1e3 * dt / a.steps:.1f} ms/step")
     if not a.no_cpu_baseline:
