@@ -857,6 +857,9 @@ struct CoopBwd2Args {
 constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over the own gate columns
 constexpr int C2_SLOTS = 4;                                 // column tiles per wave (layer 2: 4, layer 1: 2 or 3)
 constexpr int C2_XW = 2 * CB_HC;                            // 384 partial columns exchanged per row (layer 1 uses 224)
+#ifndef C2_XROUND
+#define C2_XROUND 1                                         // ring round of the own-tile pass in which the partner's partials are requested
+#endif
 
 // B fragment (cu, wave, kk, slot): [cu][wave][kk][slot][lane][8]
 __device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) {
@@ -867,10 +870,11 @@ __device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) 
 }
 
 // one pass over the own K (24 k-steps) for up to two of this wave's column tiles (slot ids s0, s1)
-// `side(i)` is called once per ring round (i = 0 .. 24/DEPTH - 1): background work spread over the GEMM
-template <int NS, typename Side>
+// `pre()` runs once, right behind the first DEPTH - 1 fragment requests (work that may wait on memory: the requests fly
+// meanwhile); `side(i)` is called once per ring round (i = 0 .. 24/DEPTH - 1): background work spread over the GEMM
+template <int NS, typename Pre, typename Side>
 __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, __amdgpu_buffer_rsrc_t wr, int cu, int wave,
-                                        int lane, int RS, int s0, int s1, Side&& side) {
+                                        int lane, int RS, int s0, int s1, Pre&& pre, Side&& side) {
   constexpr int DEPTH = 4;
   bf16x8 b[DEPTH][2];
   auto loadb = [&](bf16x8(&bb)[2], int kk) {
@@ -888,6 +892,7 @@ __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
   };
 #pragma unroll
   for (int d = 0; d < DEPTH - 1; ++d) loadb(b[d], d);
+  pre();
 #pragma unroll 1
   for (int kk = 0; kk < C2_NKK; kk += DEPTH) {
     side(kk / DEPTH);
@@ -922,14 +927,12 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
   constexpr int RSA = CB_KC + 8;                            // A tile row stride (elements): own gate columns only
   constexpr int TPR = NT / MC, UPT = HC / TPR;              // 24 threads per row, 8 units per thread
-  constexpr int XCH_CH = MC * C2_XW * 2 / 16;               // 16-byte chunks of one partial slab (1536)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Abuf = reinterpret_cast<T*>(smem_raw);                                          // [32][RSA]   own dgates
   float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)MC * RSA * sizeof(T));  // [32][HC]    d h1 (own units)
   float* dhrec2 = dh1buf + MC * HC;                                                   // [32][HC]    d h2 recurrent
   float* dxbuf = dhrec2 + MC * HC;                                                    // [32][32]    own d x partial
-  T* stage = reinterpret_cast<T*>(dxbuf + MC * 32);                                   // [32][384]   partials for the partner
-  T* whs = stage + MC * C2_XW;                                                        // HEAD: [HC][16] own units' head weights
+  T* whs = reinterpret_cast<T*>(dxbuf + MC * 32);                                     // HEAD: [HC][16] own units' head weights
   T* dys = whs + HC * 16;                                                             // HEAD: [32][16]  dY rows of one step
 
 #ifdef C2_STAMP
@@ -1038,47 +1041,33 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       *reinterpret_cast<u32x4*>(Abuf + prow * RSA + 8 * c) = out;
     }
   };
-  // partials for the partner: stage [32][384] -> exchange slab (write-through, coalesced), drained, flagged
-  auto publish = [&](int layer, int ep) {
-    const int base = ((layer * 2 + (ep & 1)) * 2 + cu) * XSL * 2;
-    for (int ch = tid; ch < XCH_CH; ch += NT)
-      store_sc1_b128(xr, base + ch * 16, *reinterpret_cast<const u32x4*>(stage + ch * 8));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Exchange of partial sums, accumulator to accumulator.  Column tile tau = wave + 12 * slot is computed by the SAME wave
+  // index on both CUs (pass 0 on the CU that does not own it, pass 1 on the owner), so the non-owner's wave ships its
+  // accumulators as they lie in registers -- per lane and tile 2 x f32x4 -> 16 bytes of bf16, lane-contiguous = coalesced
+  // write-through stores straight from the MFMA results, no LDS staging, no scatter -- and the owner's wave fetches the
+  // same 16 bytes per lane during ITS pass over the own tiles and adds them in registers before its one scatter.
+  // (Round 2 staged the partials row-major in LDS, published the slab, and added the partner's slab into the fp32 LDS
+  // buffers in a phase of its own: poll + barrier + exposed load latency + LDS read-modify-write + barrier = 8 % of a
+  // layer-step, twice per step.)  Slab (layer, parity, producing cu): [wave 12][tile-of-pass 2][lane 64][16 B] = 24 KB.
+  auto pack_acc = [](const f32x4 (&acc)[2]) {
+    u32x4 o;
+    o[0] = (uint32_t)f2bf(acc[0][0]) | ((uint32_t)f2bf(acc[0][1]) << 16);
+    o[1] = (uint32_t)f2bf(acc[0][2]) | ((uint32_t)f2bf(acc[0][3]) << 16);
+    o[2] = (uint32_t)f2bf(acc[1][0]) | ((uint32_t)f2bf(acc[1][1]) << 16);
+    o[3] = (uint32_t)f2bf(acc[1][2]) | ((uint32_t)f2bf(acc[1][3]) << 16);
+    return o;
   };
-  // partner's partials of MY outputs: added into the fp32 LDS buffers (layer 2: d h1 | d h2 rec; layer 1: d h1 rec | d x)
-  auto consume = [&](int layer, int ep) {
-    if (wave == 0) {
-      if (lane == 0) {
-        unsigned spins = 0;
-        while (CF_POLL && __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ep) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > SPIN_LIMIT) {
-            __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
-    const int base = ((layer * 2 + (ep & 1)) * 2 + pcu) * XSL * 2;
-    const int ncol = layer == 1 ? C2_XW : HC + 32;                      // valid partial columns per row
-    for (int ch = tid; ch < XCH_CH; ch += NT) {
-      const int r = ch / (C2_XW / 8), c0 = (ch % (C2_XW / 8)) * 8;
-      if (c0 >= ncol) continue;
-      const u32x4 v = load_sc1_b128(xr, base + ch * 16);
-      float* dst = c0 < HC ? dh1buf + r * HC + c0 : (layer == 1 ? dhrec2 + r * HC + (c0 - HC) : dxbuf + r * 32 + (c0 - HC));
+  auto add_packed = [](f32x4 (&acc)[2], const u32x4 v) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dst[2 * i] += __uint_as_float(v[i] << 16);
-        dst[2 * i + 1] += __uint_as_float(v[i] & 0xffff0000u);
-      }
+    for (int mt = 0; mt < 2; ++mt) {
+      acc[mt][0] += __uint_as_float(v[2 * mt] << 16);
+      acc[mt][1] += __uint_as_float(v[2 * mt] & 0xffff0000u);
+      acc[mt][2] += __uint_as_float(v[2 * mt + 1] << 16);
+      acc[mt][3] += __uint_as_float(v[2 * mt + 1] & 0xffff0000u);
     }
   };
-  // one 16-column tile of accumulators (slot sl of this wave: column tile tau = wave + 12*sl) -> the fp32 LDS buffer of
-  // the outputs this CU owns, or (bf16) the staging slab of partials for the partner
+  // one 16-column tile of accumulators (slot sl of this wave: column tile tau = wave + 12*sl, owned by this CU) -> the
+  // fp32 LDS buffer of the outputs
   auto scatter = [&](const f32x4 (&acc)[2], int sl, int layer) {
     // the lane-dependent part of every address below is re-derived from an opaque copy of (n, q) on each call: as loop
     // invariants the compiler hoisted ~50 precomputed addresses out of the time loop and spilled them to scratch, whose
@@ -1086,22 +1075,16 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     int n = n_, q = q_;
     asm volatile("" : "+v"(n), "+v"(q));
     const int tau = wave + CB_NW * sl;
-    int owner, col, ld_own = HC;
+    int ld_own = HC;
     float* own_dst;
     bool overwrite = true;
     if (layer == 1) {          // LSTM layer 2: tiles 0-23 d h1 (accumulate onto the recurrent part), 24-47 d h2 rec
       const int blk = tau / 24, tt = tau % 24;
-      owner = tt / 12;
-      col = blk * HC + (tt % 12) * 16;
       own_dst = (blk == 0 ? dh1buf : dhrec2) + (tt % 12) * 16;
       overwrite = blk == 1;
     } else if (tau < 24) {     // LSTM layer 1: tiles 0-23 d h1 rec
-      owner = tau / 12;
-      col = (tau % 12) * 16;
       own_dst = dh1buf + (tau % 12) * 16;
     } else {                   // LSTM layer 1: tiles 24-27 d x (columns 0-31 -> cu 0, 32-63 -> cu 1)
-      owner = (tau - 24) / 2;
-      col = HC + ((tau - 24) % 2) * 16;
       own_dst = dxbuf + ((tau - 24) % 2) * 16;
       ld_own = 32;
     }
@@ -1109,45 +1092,82 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int r = 16 * mt + 4 * q + j;
-        const float v = acc[mt][j];
-        if (owner == cu) {
-          float* d = own_dst + r * ld_own + n;
-          *d = overwrite ? v : *d + v;
-        } else {
-          stage[r * C2_XW + col + n] = f2bf(v);
-        }
+        float* d = own_dst + (16 * mt + 4 * q + j) * ld_own + n;
+        *d = overwrite ? acc[mt][j] : *d + acc[mt][j];
       }
   };
-  // the backward GEMM of one layer in two passes: first the column tiles the PARTNER owns (published at once, so the
-  // hand-off flies during the second pass), then the own ones; then the partner's partials are added
+  // the backward GEMM of one layer in two passes: first the column tiles the PARTNER owns (shipped at once, so the
+  // hand-off flies during the second pass), then the own ones, to which the partner's partials are added in registers
   auto layer_gemm = [&](int layer, __amdgpu_buffer_rsrc_t wr, int ep) {
     const bool l2 = layer == 1;
     const bool xw = !l2 && wave < 4;                   // this wave also has a d x tile (slot 2)
     const int xo = wave >> 1;                          // ... owned by CU xo
-    for (int pass = 0; pass < 2; ++pass) {
-      const int who = pass == 0 ? pcu : cu;            // owner of the tiles of this pass
-      const int s0 = who, s1 = l2 ? who + 2 : 2;
-      const bool two = l2 || (xw && xo == who);
-      f32x4 acc[2][2];
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int slab = ((layer * 2 + (ep & 1)) * 2) * XSL * 2;                      // byte offset of (layer, parity); + cu * XSL * 2
+    const int my = (wave * 2 * 64 + ln) * 16;                                     // this lane's 16 bytes of tile 0; tile 1: + 1024
+    f32x4 acc[2][2];
+    {   // ---- pass 0: the partner's tiles
+      const int s0 = pcu, s1 = l2 ? pcu + 2 : 2;
+      const bool two = l2 || (xw && xo == pcu);
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto none = []() {};
       auto side = [](int) {};
-      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, side);
-      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, side);
-      if (l2) { if (pass == 0) { C2T(3) } else { C2T(6) } }
-      scatter(acc[0], s0, layer);
-      if (two) scatter(acc[1], s1, layer);
-      if (pass == 0) {
-        __syncthreads();                               // staging slab complete
-        if (l2) { C2T(4) }
-        publish(layer, ep);
+      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, none, side);
+      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, none, side);
+      if (l2) { C2T(3) }
+      store_sc1_b128(xr, slab + cu * XSL * 2 + my, pack_acc(acc[0]));
+      if (two) store_sc1_b128(xr, slab + cu * XSL * 2 + my + 1024, pack_acc(acc[1]));
+      if (l2) { C2T(4) }
+    }
+    {   // ---- pass 1: the own tiles
+      const int s0 = cu, s1 = l2 ? cu + 2 : 2;
+      const bool two = l2 || (xw && xo == cu);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // behind the first fragment requests: every wave's partial stores acknowledged -> barrier -> epoch flag
+      auto pre = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (l2) { C2T(5) }
+      };
+      // the partner's partials of these tiles: every wave looks at the partner's epoch itself (requested in ring round
+      // C2_XROUND - 1, examined in round C2_XROUND: by then it has normally arrived, the bounded poll is the exception) and
+      // then requests its 16 bytes per lane and tile; they arrive during the remaining rounds
+      unsigned fl = 0;
+      u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
+      auto request = [&]() {
+        unsigned spins = 0;
+        while (CF_POLL && fl < (unsigned)ep) {
+          __builtin_amdgcn_s_sleep(1);
+          fl = __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        p0 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my);
+        if (two) p1 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my + 1024);
+      };
+      auto side = [&](int i) {
+        if (i == C2_XROUND - 1) fl = __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i == C2_XROUND) request();
+      };
+      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, pre, side);
+      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, pre, side);
+      if (C2_XROUND >= C2_NKK / 4) request();            // (diagnostic builds: no overlap with the GEMM)
+      if (l2) { C2T(6) }
+      add_packed(acc[0], p0);
+      scatter(acc[0], s0, layer);
+      if (two) {
+        add_packed(acc[1], p1);
+        scatter(acc[1], s1, layer);
       }
     }
     if (l2) { C2T(7) }
-    consume(layer, ep);                                // (barrier inside: own partials complete before the adds)
-    __syncthreads();
+    __syncthreads();                                   // the layer's outputs complete in LDS
     if (l2) { C2T(8) }
   };
 
@@ -1230,7 +1250,9 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     C2T(10)
     layer_gemm(0, wr1, ep);                            // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
     C2T(11)
-    for (int i = tid; i < MC * 32; i += NT) {
+    int ti = tid;
+    asm volatile("" : "+v"(ti));                         // (a hoisted per-lane d x address was spilled: its reload sat behind the barrier)
+    for (int i = ti; i < MC * 32; i += NT) {
       const int r = i / 32, c = i % 32;
       if (row0 + r < N) store1_nt<T>(dx + ((size_t)t * N + row0 + r) * KX + cu * 32 + c, dxbuf[i]);
     }
@@ -1471,7 +1493,7 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dyt, whT};
   hipStream_t s = (hipStream_t)stream;
   constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
-                          (size_t)CB_MC * C2_XW * 2 + (size_t)(CB_HC + CB_MC) * 16 * 2;
+                          (size_t)(CB_HC + CB_MC) * 16 * 2;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
   const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)
                       : reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<false>);

@@ -3,8 +3,9 @@
   python tools/diag/bwd2_variants.py              (GPU box: one process per variant, C2 shape N=4096, T'=253, fused head)"""
 import glob, os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-VARIANTS = {"base": [], "rawbar": ["-DC2_RAWBAR"], "nodg": ["-DC2_NO_DG"], "nofetch": ["-DC2_NO_FETCH"],
-            "rawbar_nodg": ["-DC2_RAWBAR", "-DC2_NO_DG"], "rawbar_nodg_nofetch": ["-DC2_RAWBAR", "-DC2_NO_DG", "-DC2_NO_FETCH"]}
+VARIANTS = {"base": [], "r02": [], "xround1": ["-DC2_XROUND=1"], "xround3": ["-DC2_XROUND=3"], "xround4": ["-DC2_XROUND=4"],
+            "xround6": ["-DC2_XROUND=6"], "nodg": ["-DC2_NO_DG"], "nofetch": ["-DC2_NO_FETCH"], "nodg_nofetch": ["-DC2_NO_DG", "-DC2_NO_FETCH"]}
+R02_REV = "817f50c"        # "r02": lstm_coop.hip of that commit (the staged exchange of round 2) for A/B on one box
 so = lambda n: os.path.join(root, "tools", "diag", f"libv_{n}.so")
 if "--build" in sys.argv:
     csrc = os.path.join(root, "generative-audio_amd", "csrc")
@@ -12,8 +13,12 @@ if "--build" in sys.argv:
             if not f.endswith("lstm_coop.hip")]
     for n, flags in VARIANTS.items():
         o = f"/tmp/lstm_coop_{n}.o"
+        src = os.path.join(csrc, "lstm_coop.hip")
+        if n == "r02":
+            src = "/tmp/lstm_coop_r02.hip"
+            open(src, "w").write(subprocess.check_output(["git", "-C", root, "show", R02_REV + ":generative-audio_amd/csrc/lstm_coop.hip"], text=True))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"),
-                               "-I" + csrc, "-Wno-unused-value", *flags, "-c", os.path.join(csrc, "lstm_coop.hip"), "-o", o])
+                               "-I" + csrc, "-Wno-unused-value", *flags, "-c", src, "-o", o])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so(n), o] + objs)
         print("built", so(n), flush=True)
     sys.exit(0)

@@ -41,5 +41,11 @@ else
   cut -c1-400 gpurun_out/${tag}_bench_c3_bf16.json
   timeout -k 10 400 python bench.py --config c5 --no-fp32 > gpurun_out/${tag}_bench_c5_bf16.json 2> gpurun_out/${tag}_bench_c5_bf16.log || { tail -n 5 gpurun_out/${tag}_bench_c5_bf16.log; exit 1; }
   cut -c1-400 gpurun_out/${tag}_bench_c5_bf16.json
+  # where the precision-matched (fp32) C2 step spends its time
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_fp32_prof -o r -- python3 $R/bench.py --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-families > $R/gpurun_out/${tag}_fp32_prof.log 2>&1
+  cd $R
+  cp $(find gpurun_out/${tag}_fp32_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_c2_fp32_kernel_stats.csv && rm -rf gpurun_out/${tag}_fp32_prof
+  head -8 gpurun_out/${tag}_c2_fp32_kernel_stats.csv | cut -c1-150
 fi
 echo EVIDENCE_DONE
