@@ -14,6 +14,7 @@
 // epoch words of the caller's flag block -- and carries on (wrong numbers, no hang).  The launchers zero the epoch words
 // only: the counter survives later launches and is cleared by the caller alone (ops_lstm.clear_coop_timeouts), so a host
 // check at any later point (trainer log interval, end of bench) still sees a time-out of ANY earlier launch.
+#include <type_traits>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -857,6 +858,15 @@ struct CoopBwd2Args {
 constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over the own gate columns
 constexpr int C2_SLOTS = 4;                                 // column tiles per wave (layer 2: 4, layer 1: 2 or 3)
 constexpr int C2_XW = 2 * CB_HC;                            // 384 partial columns exchanged per row (layer 1 uses 224)
+#ifndef C2_FSPLIT
+#define C2_FSPLIT 0                                         // saved-state chunks (of 4) requested behind pass 0; the rest behind pass 1
+#endif
+#ifndef C2_DEPTH
+#define C2_DEPTH 4                                          // fragment ring: C2_DEPTH - 1 k-steps requested ahead
+#endif
+#ifndef C2_KBAR
+#define C2_KBAR 8                                           // k-steps between the in-pass barriers that keep the waves in step (0: none)
+#endif
 #ifndef C2_XROUND
 #define C2_XROUND 1                                         // ring round of the own-tile pass in which the partner's partials are requested
 #endif
@@ -869,49 +879,105 @@ __device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) 
   return ((((cu * CB_NW + wave) * C2_NKK + kk) * C2_SLOTS + slot) * 512) * 2;
 }
 
-// one pass over the own K (24 k-steps) for up to two of this wave's column tiles (slot ids s0, s1)
-// `pre()` runs once, right behind the first DEPTH - 1 fragment requests (work that may wait on memory: the requests fly
-// meanwhile); `side(i)` is called once per ring round (i = 0 .. 24/DEPTH - 1): background work spread over the GEMM
-template <int NS, typename Pre, typename Side>
-__device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, __amdgpu_buffer_rsrc_t wr, int cu, int wave,
-                                        int lane, int RS, int s0, int s1, Pre&& pre, Side&& side) {
-  constexpr int DEPTH = 4;
+// ---- weight-fragment ring of the K-split backward, with hand-counted waits --------------------------------------------
+// The compiler's wait-count insertion cannot follow a register ring through a loop: for the rolled loop of round 2 it
+// emitted vmcnt(7,6),(5,4),(3,2),(1,0) within every four k-steps, i.e. the ring was DRAINED by the fourth k-step of each
+// round (prefetch distance 3 -> 0), and any other request placed inside the pass (the partner's partials, the next
+// phase's saved state) was waited for right there.  Here the pass is fully unrolled, the fragment requests go out
+// through inline asm (invisible to the pass), and every wait is `s_waitcnt vmcnt(M)` with M = the number of vector-memory
+// operations issued AFTER the fragment pair that is about to be used -- ring requests plus whatever the hooks below
+// issue at their fixed places (the hooks declare their operation counts).  vmcnt retires in order, so M younger
+// operations may still be in flight.  M must never exceed the true count; operations the model does not know (the rare
+// poll loop) only make a wait stricter.
+__device__ __forceinline__ bf16x8 c2_ring_load(const unsigned char* frag /* wave-uniform: start of the 1 KB fragment */, int lane16) {
+  bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane16), "s"(frag) : "memory");
+  return v;
+}
+// wait until at most m vector-memory operations are outstanding; the fragment registers pass through the statement, so
+// nothing that reads them can be scheduled above it
+__device__ __forceinline__ void c2_wait(int m, bf16x8& x, bf16x8& y) {
+#define C2_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x), "+v"(y)); break;
+  switch (m) {
+    C2_W(0) C2_W(1) C2_W(2) C2_W(3) C2_W(4) C2_W(5) C2_W(6) C2_W(7) C2_W(8) C2_W(9) C2_W(10) C2_W(11) C2_W(12) C2_W(13) C2_W(14)
+    C2_W(15) C2_W(16) C2_W(17) C2_W(18) C2_W(19) C2_W(20) C2_W(21) C2_W(22) C2_W(23) C2_W(24) C2_W(25) C2_W(26) C2_W(27) C2_W(28)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x), "+v"(y)); break;
+  }
+#undef C2_W
+}
+// (one fragment: the same variable must not be tied to two operands -- the second tie is a COPY made in front of the wait)
+__device__ __forceinline__ void c2_wait(int m, bf16x8& x) {
+#define C2_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x)); break;
+  switch (m) {
+    C2_W(0) C2_W(1) C2_W(2) C2_W(3) C2_W(4) C2_W(5) C2_W(6) C2_W(7) C2_W(8) C2_W(9) C2_W(10) C2_W(11) C2_W(12) C2_W(13) C2_W(14)
+    C2_W(15) C2_W(16) C2_W(17) C2_W(18) C2_W(19) C2_W(20) C2_W(21) C2_W(22) C2_W(23) C2_W(24) C2_W(25) C2_W(26) C2_W(27) C2_W(28)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); break;
+  }
+#undef C2_W
+}
+
+// One pass over the own K (24 k-steps) for NS (1 or 2) of this wave's column tiles (slot ids s0, s1).  Program order:
+//   requests for k-steps 0 .. D-1;  pre();  for k = 0..23: { k % 4 == 0: side(k / 4);  request k + D;  k == 23 - D: post();
+//   wait;  MFMAs of k-step k }      (D = C2_DEPTH - 1).
+// side(i) issues SOPS(i) vector-memory operations, post() issues POPS (both compile-time), pre() issues none that are
+// still outstanding when it returns.
+template <int NS, int XR /* partner-partials round of the own-tile pass, < 0: none */, int POPS, typename Pre, typename Side, typename Post>
+__device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, const unsigned char* wbase /* (cu, wave) */,
+                                        int lane, int RS, int s0, int s1, Pre&& pre, Side&& side, Post&& post) {
+  constexpr int DEPTH = C2_DEPTH, D = DEPTH - 1, NK = C2_NKK;      // D = prefetch distance in k-steps
+  static_assert(DEPTH >= 2 && D <= 8 && (XR < 0 || 4 * XR + D < NK), "ring depth / partner round out of the wait model's range");
   bf16x8 b[DEPTH][2];
-  auto loadb = [&](bf16x8(&bb)[2], int kk) {
-    bb[0] = BFrag<bf16_t>::load(wr, lane, c2_frag_boff(cu, wave, kk, s0));
-    if (NS == 2) bb[1] = BFrag<bf16_t>::load(wr, lane, c2_frag_boff(cu, wave, kk, s1));
+  int lane16 = lane * 16;
+  asm volatile("" : "+v"(lane16));
+  auto sops = [](int i) { return XR < 0 ? 0 : (i == XR - 1 ? 1 : 0) + (i == XR ? NS : 0); };
+  const unsigned char* w0 = wbase + s0 * 1024;
+  const unsigned char* w1 = wbase + s1 * 1024;
+  asm volatile("" : "+s"(w0), "+s"(w1));        // opaque per pass: as loop invariants of the time loop the 2 x 24 fragment addresses were spilled
+  auto request = [&](bf16x8(&bb)[2], int kk) {
+    bb[0] = c2_ring_load(w0 + kk * (C2_SLOTS * 1024), lane16);
+    if (NS == 2) bb[1] = c2_ring_load(w1 + kk * (C2_SLOTS * 1024), lane16);
   };
-  auto compute = [&](const bf16x8(&bb)[2], int kk) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) request(b[d], d);
+  pre();
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    if (k % 4 == 0) side(k / 4);
+    if (k + D < NK) request(b[(k + D) % DEPTH], k + D);
+    if (k + D == NK - 1) post();
+    // keep the twelve waves of the workgroup in step (requests stay in flight across the barrier): left alone, the oldest
+    // wave wins every arbitration and finishes a pass in 6.5k cycles, the youngest needs 14.5k, and the tail of the pass
+    // runs on the few bytes the last waves keep in flight
+    if (C2_KBAR > 0 && k > 0 && k % C2_KBAR == 0) asm volatile("s_barrier" ::: "memory");
+    // younger than the pair of k-step k: the ring requests of k+1 .. min(k+D, 23); side(i) for every round boundary
+    // 4i in (issue position of pair k, k]; post() once it has run (k >= 23 - D)
+    int m = NS * ((k + D < NK ? k + D : NK - 1) - k);
+    const int lo = k >= D ? k - D + 1 : 0;                  // pair k was requested at loop position k - D, behind that position's side()
+#pragma unroll
+    for (int p = lo; p <= k; ++p)
+      if (p % 4 == 0) m += sops(p / 4);
+    if (k >= NK - 1 - D) m += POPS;
+    if constexpr (NS == 2) c2_wait(m, b[k % DEPTH][0], b[k % DEPTH][1]);
+    else c2_wait(m, b[k % DEPTH][0]);
     bf16x8 af[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RS + 32 * kk);
+    for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RS + 32 * k);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[s][mt] = mma16(af[mt], bb[s], acc[s][mt]);
-  };
-#pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d) loadb(b[d], d);
-  pre();
-#pragma unroll 1
-  for (int kk = 0; kk < C2_NKK; kk += DEPTH) {
-    side(kk / DEPTH);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int kl = kk + d + DEPTH - 1;
-      if (kl < C2_NKK) loadb(b[(d + DEPTH - 1) % DEPTH], kl);
-      compute(b[d], kk + d);
-    }
+      for (int mt = 0; mt < 2; ++mt) acc[s][mt] = mma16(af[mt], b[k % DEPTH][s], acc[s][mt]);
   }
-  static_assert(C2_NKK % DEPTH == 0, "ring depth divides the k-steps");
 }
 
 // diagnostic phase timers (tools/diag/stamp_bwd2.py builds with -DC2_STAMP): thread 0 of workgroup 0 accumulates
 // s_memtime deltas per phase and leaves them behind the flag words
 #ifdef C2_STAMP
+#ifndef C2_STAMP_TID
+#define C2_STAMP_TID 0
+#endif
 #define C2_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define C2T(i) if (blockIdx.x == 0 && tid == 0) { const unsigned long long nw = __builtin_readcyclecounter(); st_acc[i] += nw - st_last; st_last = nw; }
-#define C2_STAMP_FINI if (blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 12; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * 2 * CB_G + 4))[i] = st_acc[i]; }
+#define C2T(i) if (blockIdx.x == 0 && tid == C2_STAMP_TID) { const unsigned long long nw = __builtin_readcyclecounter(); st_acc[i] += nw - st_last; st_last = nw; }
+#define C2_STAMP_FINI if (blockIdx.x == 0 && tid == C2_STAMP_TID) { for (int i = 0; i < 12; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * 2 * CB_G + 4))[i] = st_acc[i]; }
 #else
 #define C2T(i)
 #endif
@@ -932,7 +998,8 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)MC * RSA * sizeof(T));  // [32][HC]    d h1 (own units)
   float* dhrec2 = dh1buf + MC * HC;                                                   // [32][HC]    d h2 recurrent
   float* dxbuf = dhrec2 + MC * HC;                                                    // [32][32]    own d x partial
-  T* whs = reinterpret_cast<T*>(dxbuf + MC * 32);                                     // HEAD: [HC][16] own units' head weights
+  float* dcbuf = dxbuf + MC * 32;                                                     // [2][32][HC] d c carried from step to step
+  T* whs = reinterpret_cast<T*>(dcbuf + 2 * MC * HC);                                 // HEAD: [HC][16] own units' head weights
   T* dys = whs + HC * 16;                                                             // HEAD: [32][16]  dY rows of one step
 
 #ifdef C2_STAMP
@@ -943,10 +1010,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   int cluster, cu;
   coop_ids(CB_G, cluster, cu);
   if (cluster >= a.clusters) return;
+#ifdef C2_WPRIO
+  if (wave >= 9) asm volatile("s_setprio 3"); else if (wave >= 6) asm volatile("s_setprio 2"); else if (wave >= 3) asm volatile("s_setprio 1");
+#endif
   const int pcu = 1 - cu;
   const long row0 = (long)cluster * MC;
   const long N = a.N;
-  for (int i = tid; i < 2 * MC * HC + MC * 32; i += NT) dh1buf[i] = 0.f;
+  for (int i = tid; i < 4 * MC * HC + MC * 32; i += NT) dh1buf[i] = 0.f;      // d h1, d h2 rec, d x, d c (both layers)
   for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
   if constexpr (HEAD) {
     const T* whT = reinterpret_cast<const T*>(a.whT);
@@ -955,9 +1025,10 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 
   const int prow = tid / TPR;
   const bool prow_ok = row0 + prow < N;
-  float dc1[UPT], dc2[UPT];
-#pragma unroll
-  for (int i = 0; i < UPT; ++i) dc1[i] = dc2[i] = 0.f;
+  // (d c of the thread's 8 units per layer lives in LDS, not in 16 registers: both layers' saved state is in flight at
+  // the end of a GEMM pass since round 3, and the registers are what that costs)
+  float* dc1 = dcbuf;
+  float* dc2 = dcbuf + MC * HC;
 
   const T* g1 = reinterpret_cast<const T*>(a.g1);
   const T* g2 = reinterpret_cast<const T*>(a.g2);
@@ -1005,39 +1076,70 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       if (dh_ext) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
     }
   };
+  // The same for the chunks j0 <= j < j1 only, always with carry, and UNCONDITIONAL (time and row indices are clamped into
+  // the tensors; what a clamped request returns is never used): this is the form used inside the time loop, from the
+  // `post` hooks of the GEMM passes -- a load that only some paths issue makes hipcc's (path-insensitive) wait-count
+  // insertion drain the whole queue in front of the next fragment use.
+  const long prow_c = row0 + prow < N ? row0 + prow : N - 1;
+  auto fetch_part = [&](auto with_dh, Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t, int j0, int j1) {
+#ifdef C2_NO_FETCH
+    return;
+#endif
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));
+    const int tcl = t > 0 ? t : 0, tpl = t > 1 ? t - 1 : 0;
+    const size_t e = ((size_t)tcl * N + prow_c) * H + cu * HC, ep = ((size_t)tpl * N + prow_c) * H + cu * HC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const int c = tc + TPR * j;
+      sv.g[j] = ld_nt16(gs + e * 4 + 8 * c);
+      sv.ct[j] = sv.cp[j];
+      sv.cp[j] = ld_nt4(cs + ep + 2 * c);
+      if constexpr (decltype(with_dh)::value) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
+    }
+  };
   auto lo16 = [](unsigned w) { return __uint_as_float(w << 16); };
   auto hi16 = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
   // cell backward -> gate gradients (bf16, local k = unit*4 + gate): LDS A operand + dg [t*N + row][4H] (own 768 columns)
-  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float (&dc)[UPT], int t, T* dg) {
+  // The phase has NO branch on the row being valid: rows past N compute on clamped (finite) saved state, their gate
+  // gradients are forced to zero for the LDS operand and their dg stores are dropped by the range check of the step's
+  // buffer descriptor (base = row 0 of time t, num_records = one time step).  A store that only some paths issue made
+  // hipcc wait for vmcnt(0) -- i.e. for the acknowledgement of the previous chunk's HBM store -- before every chunk.
+  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float* dcl, int t, T* dg) {
     int tc = tc_;
     asm volatile("" : "+v"(tc));
+    const __amdgpu_buffer_rsrc_t dgr = make_rsrc(dg + (size_t)t * N * CB_K4, (unsigned)((size_t)N * CB_K4 * sizeof(T)));
+    const int rowoff = (int)(((row0 + prow) * CB_K4 + cu * CB_KC) * sizeof(T));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = tc + TPR * j;
-      u32x4 out = {0u, 0u, 0u, 0u};
-      if (prow_ok) {
+      u32x4 out;
+      float2 dcv = *reinterpret_cast<const float2*>(dcl + prow * HC + 2 * c);
+      const float2 dhv = *reinterpret_cast<const float2*>(dh_lds + prow * HC + 2 * c);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const unsigned w0 = sv.g[j][2 * e], w1 = sv.g[j][2 * e + 1];   // (i, g), (f, o) of unit 2c + e
-          const float iv = lo16(w0), gv = hi16(w0), fv = lo16(w1), ov = hi16(w1);
-          const float ct = e ? hi16(sv.ct[j]) : lo16(sv.ct[j]);
-          const float cp = t > 0 ? (e ? hi16(sv.cp[j]) : lo16(sv.cp[j])) : 0.f;
-          float dh = dh_lds[prow * HC + 2 * c + e];
-          if (has_ext) dh += e ? hi16(sv.dh[j]) : lo16(sv.dh[j]);
-          const float tch = tanh_f(ct);
-          const float dct = dh * ov * (1.f - tch * tch) + dc[2 * j + e];
-          const float dO = dh * tch * ov * (1.f - ov);
-          const float di = dct * gv * iv * (1.f - iv);
-          const float dgg = dct * iv * (1.f - gv * gv);
-          const float df = dct * cp * fv * (1.f - fv);
-          dc[2 * j + e] = dct * fv;
-          out[2 * e] = (uint32_t)f2bf(di) | ((uint32_t)f2bf(dgg) << 16);
-          out[2 * e + 1] = (uint32_t)f2bf(df) | ((uint32_t)f2bf(dO) << 16);
-        }
-#ifndef C2_NO_DG
-        st_nt16(dg + ((size_t)t * N + row0 + prow) * CB_K4 + cu * CB_KC + 8 * c, out);
-#endif
+      for (int e = 0; e < 2; ++e) {
+        const unsigned w0 = sv.g[j][2 * e], w1 = sv.g[j][2 * e + 1];   // (i, g), (f, o) of unit 2c + e
+        const float iv = lo16(w0), gv = hi16(w0), fv = lo16(w1), ov = hi16(w1);
+        const float ct = e ? hi16(sv.ct[j]) : lo16(sv.ct[j]);
+        const float cp = t > 0 ? (e ? hi16(sv.cp[j]) : lo16(sv.cp[j])) : 0.f;
+        float dh = e ? dhv.y : dhv.x;
+        if (has_ext) dh += e ? hi16(sv.dh[j]) : lo16(sv.dh[j]);
+        const float tch = tanh_f(ct);
+        const float dct = dh * ov * (1.f - tch * tch) + (e ? dcv.y : dcv.x);
+        const float dO = dh * tch * ov * (1.f - ov);
+        const float di = dct * gv * iv * (1.f - iv);
+        const float dgg = dct * iv * (1.f - gv * gv);
+        const float df = dct * cp * fv * (1.f - fv);
+        if (e) dcv.y = dct * fv; else dcv.x = dct * fv;
+        out[2 * e] = (uint32_t)f2bf(di) | ((uint32_t)f2bf(dgg) << 16);
+        out[2 * e + 1] = (uint32_t)f2bf(df) | ((uint32_t)f2bf(dO) << 16);
       }
+      if (!prow_ok) { out = u32x4{0u, 0u, 0u, 0u}; dcv = float2{0.f, 0.f}; }
+      *reinterpret_cast<float2*>(dcl + prow * HC + 2 * c) = dcv;
+#ifndef C2_NO_DG
+      __builtin_amdgcn_raw_buffer_store_b128(out, dgr, rowoff + 16 * c, 0, 2);       // aux 2 = nt
+#endif
       *reinterpret_cast<u32x4*>(Abuf + prow * RSA + 8 * c) = out;
     }
   };
@@ -1098,8 +1200,37 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   };
   // the backward GEMM of one layer in two passes: first the column tiles the PARTNER owns (shipped at once, so the
   // hand-off flies during the second pass), then the own ones, to which the partner's partials are added in registers
-  auto layer_gemm = [&](int layer, __amdgpu_buffer_rsrc_t wr, int ep) {
-    const bool l2 = layer == 1;
+  // HEAD: the head's contribution to d h2_tau, dY_tau . Wh restricted to the own units, is formed here: the 32 dY rows of a
+  // step (1 KB) arrive by ONE LDS-DMA instruction, every wave turns them into its 16-unit column tile with two MFMAs and
+  // adds the tile to dhrec2 -- no dh2 tensor is written by a head kernel or fetched with the saved state.  The DMA is
+  // issued by EVERY wave (same source, same destination, same bytes: 11 redundant L2 hits per step) and for tau = -1 too
+  // (clamped): an instruction that only one wave / some steps issue is one more conditional memory operation for the
+  // wait-count insertion to be pessimistic about.
+  const __amdgpu_buffer_rsrc_t dyr = make_rsrc(a.dyt, HEAD ? (unsigned)((size_t)a.Tn * N * 16 * sizeof(T)) : 0u);
+  auto dy_dma = [&](int tau) {
+    if constexpr (HEAD) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      const int tcl = tau > 0 ? tau : 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void*)dys, 16, lane * 16,
+                                               (int)((((size_t)tcl * N + row0) * 16) * sizeof(T)), 0, 0);
+    }
+  };
+  // `nsv` ... : the saved state of THIS layer's next (earlier) step, requested behind the last fragment request of each
+  // pass (its registers are free: this step's cell phase of the layer is over): C2_FSPLIT chunks behind pass 0, where the
+  // wave waits for its partial stores anyway, the rest behind pass 1, with the scatter, the barrier and the other layer's
+  // whole cell phase (ALU + LDS only) to arrive before the next GEMM's fragment ring queues up behind it.  (Round 2
+  // requested a phase's state right in front of the previous cell phase: 61 KB per CU take longer than that phase, and
+  // the first fragments of the following GEMM waited out the difference.)
+  auto layer_gemm = [&](auto layer_c, const void* wpacked, int ep, Saved& nsv, const T* ngs, const T* ncs, const T* ndh, int nt) {
+    constexpr int layer = decltype(layer_c)::value;
+    constexpr bool l2 = layer == 1;
+    typedef std::integral_constant<bool, l2 && !HEAD> with_dh;             // only layer 2 without the fused head reads d h2
+#ifdef C2_NO_FETCH
+    constexpr int P0 = 0, P1 = 0;
+#else
+    constexpr int P0 = C2_FSPLIT * (2 + (with_dh::value ? 1 : 0)), P1 = (4 - C2_FSPLIT) * (2 + (with_dh::value ? 1 : 0));
+#endif
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wpacked) + (size_t)(cu * CB_NW + wave) * (C2_NKK * C2_SLOTS * 1024);
     const bool xw = !l2 && wave < 4;                   // this wave also has a d x tile (slot 2)
     const int xo = wave >> 1;                          // ... owned by CU xo
     int ln = lane;
@@ -1114,9 +1245,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto none = []() {};
       auto side = [](int) {};
-      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, none, side);
-      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, none, side);
+      auto post = [&]() { fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, C2_FSPLIT); };
+      if (two) c2_gemm<2, -1, P0>(acc, a_lane, wbase, lane, RSA, s0, s1, none, side, post);
+      else c2_gemm<1, -1, P0>(acc, a_lane, wbase, lane, RSA, s0, s1, none, side, post);
       if (l2) { C2T(3) }
+      // HEAD: the dY rows of the next (earlier) step -- here, where the wave is about to wait for its partial stores anyway
+      // (in front of the cell phase their DMA sat in the queue that the phase's first use of the saved state waits on)
+      if (l2) dy_dma(nt);
       store_sc1_b128(xr, slab + cu * XSL * 2 + my, pack_acc(acc[0]));
       if (two) store_sc1_b128(xr, slab + cu * XSL * 2 + my + 1024, pack_acc(acc[1]));
       if (l2) { C2T(4) }
@@ -1137,26 +1272,36 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       // C2_XROUND - 1, examined in round C2_XROUND: by then it has normally arrived, the bounded poll is the exception) and
       // then requests its 16 bytes per lane and tile; they arrive during the remaining rounds
       unsigned fl = 0;
+      int zoff = 0;
+      asm volatile("" : "+v"(zoff));
+      const gu32* pflag = flags + layer * CB_G + pcu;
       u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
       auto request = [&]() {
         unsigned spins = 0;
-        while (CF_POLL && fl < (unsigned)ep) {
-          __builtin_amdgcn_s_sleep(1);
-          fl = __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (++spins > SPIN_LIMIT) {
+        while (CF_POLL && fl < (unsigned)ep) {            // (no exit with a request still pending: the compiler would wait
+          if (++spins > SPIN_LIMIT) {                     //  for it -- and with it for the whole ring -- behind the loop)
             if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
+          __builtin_amdgcn_s_sleep(1);
+          fl = __hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         p0 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my);
         if (two) p1 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my + 1024);
       };
-      auto side = [&](int i) {
-        if (i == C2_XROUND - 1) fl = __hip_atomic_load(flags + layer * CB_G + pcu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (i == C2_XROUND) request();
+      // (the epoch request goes out through inline asm and is waited for by hand, like the ring: the compiler, which does
+      // not see the ring requests, would wait for vmcnt(0) before the first use of the value)
+      auto side = [&](auto nsc, int i) {
+        if (i == C2_XROUND - 1) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(fl) : "v"(zoff), "s"(pflag) : "memory");
+        if (i == C2_XROUND) {
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(fl) : "n"(4 * decltype(nsc)::value));     // younger: one round (4 k-steps) of ring requests
+          request();
+        }
       };
-      if (two) c2_gemm<2>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, pre, side);
-      else c2_gemm<1>(acc, a_lane, wr, cu, wave, lane, RSA, s0, s1, pre, side);
+      auto post = [&]() { fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, C2_FSPLIT, 4); };
+      constexpr int XR = C2_XROUND < C2_NKK / 4 ? C2_XROUND : -1;
+      if (two) c2_gemm<2, XR, P1>(acc, a_lane, wbase, lane, RSA, s0, s1, pre, [&](int i) { side(std::integral_constant<int, 2>{}, i); }, post);
+      else c2_gemm<1, XR, P1>(acc, a_lane, wbase, lane, RSA, s0, s1, pre, [&](int i) { side(std::integral_constant<int, 1>{}, i); }, post);
       if (C2_XROUND >= C2_NKK / 4) request();            // (diagnostic builds: no overlap with the GEMM)
       if (l2) { C2T(6) }
       add_packed(acc[0], p0);
@@ -1171,19 +1316,6 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     if (l2) { C2T(8) }
   };
 
-  // HEAD: the head's contribution to d h2_tau, dY_tau . Wh restricted to the own units, is formed here: the 32 dY rows of a
-  // step (1 KB) arrive by ONE LDS-DMA instruction of wave 0, every wave turns them into its 16-unit column tile with two
-  // MFMAs and adds the tile to dhrec2 -- no dh2 tensor is written by a head kernel or fetched with the saved state
-  const __amdgpu_buffer_rsrc_t dyr = make_rsrc(a.dyt, HEAD ? (unsigned)((size_t)a.Tn * N * 16 * sizeof(T)) : 0u);
-  auto dy_dma = [&](int tau) {
-    if constexpr (HEAD) {
-      if (wave == 0 && tau >= 0) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void*)dys, 16, lane * 16,
-                                                 (int)((((size_t)tau * N + row0) * 16) * sizeof(T)), 0, 0);
-      }
-    }
-  };
   auto head_add = [&]() {
     if constexpr (HEAD) {
       int nn = lane & 15, qq = lane >> 4;
@@ -1204,6 +1336,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 
   Saved sv2, sv1;
   fetch(sv2, g2, c2, dh2_src, a.Tn - 1, false);
+  fetch(sv1, g1, c1, nullptr, a.Tn - 1, false);
   if constexpr (HEAD) {
     dy_dma(a.Tn - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1218,15 +1351,12 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 #pragma unroll 1
   for (int t = a.Tn - 1; t >= 0; --t) {
     const int ep = a.Tn - t;
-    // The saved state of the NEXT phase is requested right before each cell phase (ALU + LDS only, ~2 us): loads, stores
-    // and the weight-fragment ring share one in-order vmcnt queue, so HBM loads issued in front of a GEMM made its
-    // first weight fragments wait out the HBM latency (~8 us per step); the wait for THIS phase's state, issued a
-    // whole layer earlier, leaves the younger loads in flight.  (Measured: issuing one phase's 84 KB of state loads
-    // occupies a CU's memory queue for ~12k cycles -- per-CU miss parallelism, not chip-wide HBM contention: starting
-    // the clusters an eighth of a step apart changed nothing.)
+    // Loads, stores and the weight-fragment ring share one in-order vmcnt queue per wave, so HBM loads issued in front of
+    // a GEMM make its first weight fragments wait out the HBM latency: the saved state of a phase is requested from inside
+    // the same layer's GEMM of the step before (layer_gemm).  (Measured: issuing one phase's 61-84 KB of state loads
+    // occupies a CU's memory queue for ~12k cycles -- per-CU miss parallelism, not chip-wide HBM contention: starting the
+    // clusters an eighth of a step apart changed nothing.)
     // ---------------- LSTM layer 2 (exchange layer index 1)
-    fetch(sv1, g1, c1, nullptr, t, t < a.Tn - 1);      // layer-1 state of this step
-    dy_dma(t - 1);                                     // HEAD: dY rows of the next (earlier) step
     cell_bwd(sv2, dhrec2, !HEAD, dc2, t, dg2T);
     C2T(0)
 #ifdef C2_RAWBAR
@@ -1236,10 +1366,9 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 #endif
     C2T(1)
     C2T(2)
-    layer_gemm(1, wr2, ep);                            // d h1_t (both contributions) and d h2_{t-1} final
+    layer_gemm(std::integral_constant<int, 1>{}, a.wb2, ep, sv2, g2, c2, dh2_src, t - 1);   // d h1_t (both contributions) and d h2_{t-1} final
     if (t > 0) head_add();                             // HEAD: + dY_{t-1} . Wh (read by the next step's cell phase, barriers between)
     // ---------------- LSTM layer 1 (exchange layer index 0)
-    fetch(sv2, g2, c2, dh2_src, t - 1, true);          // layer-2 state of the next (earlier) step
     cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
     C2T(9)
 #ifdef C2_RAWBAR
@@ -1248,7 +1377,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     __syncthreads();
 #endif
     C2T(10)
-    layer_gemm(0, wr1, ep);                            // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
+    layer_gemm(std::integral_constant<int, 0>{}, a.wb1, ep, sv1, g1, c1, nullptr, t - 1);   // d h1_{t-1} (recurrent) and this CU's 32 columns of d x final
     C2T(11)
     int ti = tid;
     asm volatile("" : "+v"(ti));                         // (a hoisted per-lane d x address was spilled: its reload sat behind the barrier)
@@ -1492,7 +1621,7 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * C2_XW * 2) return NPPC_EBADARG;
   CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dyt, whT};
   hipStream_t s = (hipStream_t)stream;
-  constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
+  constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)4 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
                           (size_t)(CB_HC + CB_MC) * 16 * 2;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
   const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)

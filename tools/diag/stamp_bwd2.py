@@ -2,10 +2,11 @@
 import sys, os, subprocess, glob
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(root, "generative-audio_amd"))
-so = os.path.join(root, "tools", "diag", "libnppc_stamp2.so")
+STID = next((a.split("=")[1] for a in sys.argv if a.startswith("--tid=")), "0")
+so = os.path.join(root, "tools", "diag", f"libnppc_stamp2_t{STID}.so")
 if "--build" in sys.argv:
     srcs = sorted(glob.glob(os.path.join(root, "generative-audio_amd", "csrc", "*.hip")))
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DC2_STAMP"] + (["-DC2_NO_DG"] if "--nodg" in sys.argv else []) + [
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DC2_STAMP", "-DC2_STAMP_TID=" + STID] + (["-DC2_NO_DG"] if "--nodg" in sys.argv else []) + [
            "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "generative-audio_amd", "csrc"), "-o", so] + srcs
     subprocess.check_call(cmd)
     sys.exit(0)
@@ -39,6 +40,6 @@ dbg = fl[ncl * 4 + 4: ncl * 4 + 4 + 24].view(torch.int64).cpu().tolist()
 names = ["P2 cell bwd", "barrier", "fetch + dg store issue", "L2 gemm pass 0 (partner tiles)", "partials: pack + store issue", "pass-1 prologue + store drain + barrier + flag",
          "L2 gemm pass 1 (own tiles; partner epoch check + partial loads inside)", "add partials + scatter own", "barrier", "P1 cell bwd", "barrier + fetch + dg store", "layer-1 gemm/exchange (all)"]
 tot = sum(dbg)
-print(f"bwd K-split: total cycles/step {tot/Tn:.0f} (100 MHz counter: {tot/Tn/100:.1f} us)")
+print(f"bwd K-split, thread {STID} of workgroup 0: total s_memtime ticks/step {tot/Tn:.0f}")
 for nme, v in zip(names, dbg):
     print(f"   {nme:44s} {v/Tn:9.1f} ticks/step  {100*v/max(tot,1):5.1f}%")
