@@ -175,6 +175,11 @@ template <> __device__ __forceinline__ void store4_nt<bf16_t>(bf16_t* p, float a
 }
 template <typename T> __device__ __forceinline__ void store1_nt(T* p, float v) { __builtin_nontemporal_store(from_f32<T>(v), p); }
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not make the wave wait for its outstanding
+// global loads / stores / LDS-DMA (hipcc emits s_waitcnt vmcnt(0) in front of the barrier whenever an LDS-DMA may be in
+// flight, and for pending stores) -- used where everything still in flight is consumed behind a LATER vmcnt(0) + barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // LDS row (elements): [X0 (KX) | X1 (KX) | H1 (H) | H2 (H)] + pad.  H = 384 = 12 k-steps.
 // diagnostic phase timers of the forward kernel (tools/diag/stamp_fwd.py builds with -DCF_STAMP)
 #ifdef CF_STAMP
@@ -848,7 +853,7 @@ struct CoopBwd2Args {
   const void* wb1; const void* wb2;   // packed by lstm_coop_pack_bwd2_kernel
   void* dx; void* dg1; void* dg2;     // dg [Tn][N][4H]
   void* xch;                          // [clusters][2 layers][2 parities][2 CUs][32][384] bf16 partial sums
-  unsigned* flags;                    // [clusters][2 layers][2] epochs + timeout word
+  unsigned* flags;                    // [clusters][2 layers][2 CUs][12 waves] epochs + 4 timeout words
   long N; int Tn; int clusters;
   // fused head backward: dyt [Tn][N][16] bf16 (dY rows, zero beyond O and before the look-ahead), whT [H][32] bf16
   // ([u][o]); the kernel forms d h2 += dY . Wh itself and dh2 is not read
@@ -857,6 +862,7 @@ struct CoopBwd2Args {
 
 constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over the own gate columns
 constexpr int C2_SLOTS = 4;                                 // column tiles per wave (layer 2: 4, layer 1: 2 or 3)
+constexpr int C2_FPC = 2 * CB_G * CB_NW;                     // epoch words per cluster: [layer 2][cu 2][wave 12] (every wave hands off its own tiles)
 constexpr int C2_XW = 2 * CB_HC;                            // 384 partial columns exchanged per row (layer 1 uses 224)
 #ifndef C2_FSPLIT
 #define C2_FSPLIT 0                                         // saved-state chunks (of 4) requested behind pass 0; the rest behind pass 1
@@ -868,7 +874,7 @@ constexpr int C2_XW = 2 * CB_HC;                            // 384 partial colum
 #define C2_KBAR 8                                           // k-steps between the in-pass barriers that keep the waves in step (0: none)
 #endif
 #ifndef C2_XROUND
-#define C2_XROUND 1                                         // ring round of the own-tile pass in which the partner's partials are requested
+#define C2_XROUND 4                                         // ring round of the own-tile pass in which the partner's partials are requested
 #endif
 
 // B fragment (cu, wave, kk, slot): [cu][wave][kk][slot][lane][8]
@@ -977,15 +983,11 @@ __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
 #endif
 #define C2_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define C2T(i) if (blockIdx.x == 0 && tid == C2_STAMP_TID) { const unsigned long long nw = __builtin_readcyclecounter(); st_acc[i] += nw - st_last; st_last = nw; }
-#define C2_STAMP_FINI if (blockIdx.x == 0 && tid == C2_STAMP_TID) { for (int i = 0; i < 12; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * 2 * CB_G + 4))[i] = st_acc[i]; }
+#define C2_STAMP_FINI if (blockIdx.x == 0 && tid == C2_STAMP_TID) { for (int i = 0; i < 12; ++i) ((unsigned long long*)(a.flags + (size_t)a.clusters * C2_FPC + 4))[i] = st_acc[i]; }
 #else
 #define C2T(i)
 #endif
 
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not make the wave wait for its outstanding
-// global loads / stores / LDS-DMA (hipcc emits s_waitcnt vmcnt(0) in front of the barrier whenever an LDS-DMA may be in
-// flight, and for pending stores) -- used where everything still in flight is consumed behind a LATER vmcnt(0) + barrier
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
@@ -1043,8 +1045,8 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   constexpr int XSL = MC * C2_XW;                                                   // elements of one partial slab
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const T*>(a.xch) + (size_t)cluster * 2 * 2 * 2 * XSL,
                                               (unsigned)(2 * 2 * 2 * XSL * sizeof(T)));
-  gu32* flags = (gu32*)(a.flags + (size_t)cluster * 2 * CB_G);
-  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * 2 * CB_G);
+  gu32* flags = (gu32*)(a.flags + (size_t)cluster * C2_FPC);
+  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * C2_FPC);
   const T* a_lane = Abuf + n * RSA + 8 * q;
   __syncthreads();
 
@@ -1261,11 +1263,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       const bool two = l2 || (xw && xo == cu);
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // behind the first fragment requests: every wave's partial stores acknowledged -> barrier -> epoch flag
+      // behind the first fragment requests: THIS wave's partial stores acknowledged -> its epoch flag.  A wave hands its
+      // tiles to the same wave of the partner, so the hand-off needs no workgroup barrier (Guideline 16 R1 per wave: the
+      // storing wave's vmcnt(0), then its flag): the waves of a workgroup drift apart by more than a third of a pass, and
+      // with a barrier here the early ones idled while the L2 pipe ran on the requests of the late ones.
       auto pre = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + layer * CB_G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(flags + (layer * CB_G + cu) * CB_NW + wave, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (l2) { C2T(5) }
       };
       // the partner's partials of these tiles: every wave looks at the partner's epoch itself (requested in ring round
@@ -1274,7 +1278,7 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
       unsigned fl = 0;
       int zoff = 0;
       asm volatile("" : "+v"(zoff));
-      const gu32* pflag = flags + layer * CB_G + pcu;
+      const gu32* pflag = flags + (layer * CB_G + pcu) * CB_NW + wave;
       u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
       auto request = [&]() {
         unsigned spins = 0;
@@ -1630,7 +1634,7 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   static int per_cu[2] = {-1, -1};
   const int fits = coop_fits(k, CB_NT, smem, clusters * CB_G, per_cu[dyt ? 1 : 0]);
   if (fits != NPPC_OK) return fits;
-  if (hipMemsetAsync(flags, 0, (size_t)clusters * 2 * CB_G * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  if (hipMemsetAsync(flags, 0, (size_t)clusters * C2_FPC * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
   if (dyt)
     hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<true>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   else

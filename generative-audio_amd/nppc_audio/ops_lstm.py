@@ -340,7 +340,7 @@ def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None, head=None):
     if use_coop and COOP_BWD_KSPLIT:
         ncl = (N + 31) // 32
         xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 384,), dt, dev)
-        flags = workspace(tag + ("coop_flags",), (ncl * 4 + 4,), torch.int32, dev, zero=True)
+        flags = workspace(tag + ("coop_flags",), (ncl * 48 + 4,), torch.int32, dev, zero=True)   # [cluster][layer][cu][wave] epochs + time-out words
         if head is not None:
             dyt, whT = head
             _timed(("lstm2_bwd_coop_ksplit", 1, N, Tn, 2), lambda: H.call(

@@ -233,7 +233,9 @@ int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const vo
                         const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes, unsigned* flags, long N,
                         int Tn, int n_cu, void* stream);
 /* K-split variant of the cooperative backward (each CU multiplies its own gate-gradient half with all output columns and
- * the pair exchanges bf16 partial sums: 38 KB per step instead of 96 KB); same tensor contract */
+ * the pair exchanges bf16 partial sums, accumulator to accumulator: 38 KB per step instead of 96 KB); same tensor contract,
+ * except flags: ceil(N / 32) * 48 + 4 u32 ([cluster][layer 2][CU 2][wave 12] epochs -- every wave hands off its own tiles --
+ * followed by the 4 sticky time-out words); xch: ceil(N / 32) * 2 * 2 * 2 * 32 * 384 bf16 */
 int nppc_lstm2_coop_bwd2_packed_elems(long* n);
 int nppc_lstm2_coop_bwd2_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
                               void* wb2, void* stream);

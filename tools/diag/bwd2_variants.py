@@ -3,9 +3,8 @@
   python tools/diag/bwd2_variants.py              (GPU box: one process per variant, C2 shape N=4096, T'=253, fused head)"""
 import glob, os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-VARIANTS = {"base": [], "r02": [], "fsplit1": ["-DC2_FSPLIT=1"], "kbar0": ["-DC2_KBAR=0"], "kbar4": ["-DC2_KBAR=4"], "depth3": ["-DC2_DEPTH=3"], "depth6": ["-DC2_DEPTH=6"],
-            "xround2": ["-DC2_XROUND=2"], "nodg": ["-DC2_NO_DG"], "nofetch": ["-DC2_NO_FETCH"], "nodg_nofetch": ["-DC2_NO_DG", "-DC2_NO_FETCH"]}
-R02_REV = "817f50c"        # "r02": lstm_coop.hip of that commit (the staged exchange of round 2) for A/B on one box
+VARIANTS = {"base": [], "r02": []}
+R02_REV = "HEAD"        # "r02" variant = lstm_coop.hip of that commit for A/B on one box
 so = lambda n: os.path.join(root, "tools", "diag", f"libv_{n}.so")
 if "--build" in sys.argv:
     csrc = os.path.join(root, "generative-audio_amd", "csrc")

@@ -36,7 +36,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 fl = [t for k, t in ops_lstm._WS.items() if k[0][-1] == "coop_flags" and k[0][0] == "lstm_bwd"][-1]
 ncl = (N + 31) // 32
-dbg = fl[ncl * 4 + 4: ncl * 4 + 4 + 24].view(torch.int64).cpu().tolist()
+dbg = fl[ncl * 48 + 4: ncl * 48 + 4 + 24].view(torch.int64).cpu().tolist()
 names = ["P2 cell bwd", "barrier", "fetch + dg store issue", "L2 gemm pass 0 (partner tiles)", "partials: pack + store issue", "pass-1 prologue + store drain + barrier + flag",
          "L2 gemm pass 1 (own tiles; partner epoch check + partial loads inside)", "add partials + scatter own", "barrier", "P1 cell bwd", "barrier + fetch + dg store", "layer-1 gemm/exchange (all)"]
 tot = sum(dbg)
