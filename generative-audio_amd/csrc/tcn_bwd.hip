@@ -508,6 +508,8 @@ __global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int 
   __shared__ float red[16][64];
   const int z = blockIdx.y, Cc = g.Cc;
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  if (blockIdx.x == 0)                                 // the per-sample sums of this launch set are consumed: zero for the next call
+    for (int i = threadIdx.x; i < B * MB_SUMS; i += 1024) g.S[(size_t)z * B * MB_SUMS + i] = 0.0;
   if ((int)blockIdx.x >= nb_main) {                   // workgroups behind the main ones: the sconv bias gradient from tile sums
     const int c = ((int)blockIdx.x - nb_main) * 64 + col;
     float s = 0.f;
@@ -603,7 +605,7 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
 
 /* fused backward of a TCNBlock's middle (GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1): dA -> dpre1 and
  * every parameter gradient of those stages plus the conv1x1 bias gradient, one reduce + one apply launch
- * (S: [batch][B][8] fp64 workspace, zeroed here; part: nppc_tcn_mid_bwd_part_elems(...) floats of workspace for the
+ * (S: [batch][B][8] fp64 workspace, ZERO on entry -- zero it once after allocation -- and left zero; part: nppc_tcn_mid_bwd_part_elems(...) floats of workspace for the
  * per-workgroup partial sums; a2 (nullable): GN2(y2) written for the sconv weight gradient) */
 int nppc_tcn_mid_bwd_part_elems(int B, int Cc, int Tp, int batch, long* n) {
   if (!n || B <= 0 || Cc <= 0 || Tp <= 0 || batch <= 0) return NPPC_EBADARG;
@@ -624,7 +626,8 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
   if (colpart && (!dbias2 || cp_tiles < 1 || cp_cols < 1 || cp_ld < cp_cols)) return NPPC_EBADARG;
   if (Cc % MB_CG) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(S, 0, sizeof(double) * MB_SUMS * B * batch, s) != hipSuccess) return NPPC_ELAUNCH;   // [batch][B][8], sSt = 2B
+  // (S is zero on entry and left zero: the finishing launch clears it behind its last reader -- one memset per block and
+  // step less on the main queue)
   MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
                dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part,
                colpart, cp_tiles, cp_ld, cp_cols, dbias2};

@@ -483,12 +483,15 @@ class FSNEngine:
             return
         # generic path (fp32 parity mode, small hidden sizes): transposed copies + the NT split-K GEMM
         bk = 64 if self.prec == H.PREC_BF16 else 32
-        Rp = rup(Rr, bk)
+        # split-K: the products are (4H x H) outputs over T'*N rows -- 72 workgroups at C2 without it, each walking a million
+        # rows (the fp32 step spent 372 of its 556 ms in these five launches, profiles/r03_bench_c2_fp32_kernel_stats.csv)
+        Sg = max(1, min(64, Rr // (16 * bk)))
+        Rp = rup(Rr, bk * Sg)
         K4p, Hp, KXp = rup(K4, 128), rup(Hd, 128), rup(KX, 128)
         dgT = [ws("dg1T", (K4p, Rp), zero=True), ws("dg2T", (K4p, Rp), zero=True)]
         for src, dst in ((dg1, dgT[0]), (dg2, dgT[1])):
             H.call("nppc_transpose", self.prec, src, dst, Rr, K4, K4, Rp, 0, 0, 0, 1, s)
-        slab = ws("slab", (K4p * max(Hp, KXp),), torch.float32)
+        slab = ws("slab", (Sg * K4p * max(Hp, KXp),), torch.float32)
         for dg, off, inp, width, dest in jobs:
             wp = rup(width, 128)
             name = f"inT_{id(inp)}_{off}"
@@ -496,8 +499,8 @@ class FSNEngine:
             # shifted product: input row r pairs with dgates row r + off -> place it at column r + off (scalar stores)
             H.call("nppc_transpose", self.prec, inp, inT.view(-1)[off:], Rr - off, width, width, Rp, 0, 0, 0, 1, s)
             A = dgT[0] if dg is dg1 else dgT[1]
-            H.call("nppc_gemm_nt_splitk", self.prec, A, Rp, inT, Rp, slab, wp, K4p, wp, Rp, 1, s)
-            scatter(slab, 1, K4p, wp, dest)
+            H.call("nppc_gemm_nt_splitk", self.prec, A, Rp, inT, Rp, slab, wp, K4p, wp, Rp, Sg, s)
+            scatter(slab, Sg, K4p, wp, dest)
 
     def backward(self, dout, gen=None):
         """dout [B', O, F', T] fp32 -> flat parameter gradient (same layout as the flat parameter buffer).
@@ -639,7 +642,7 @@ class FSNEngine:
         sAct = B * Tp * TCN_HIDDEN
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
-        Smid = ws("Smid", (3, B, 8), torch.float64)
+        Smid = ws("Smid", (3, B, 8), torch.float64, zero=True)      # zero on entry, left zero by every call
         Pmid = ws("Pmid", (H.mid_bwd_part_elems(B, TCN_HIDDEN, Tp, 3),), torch.float32)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):

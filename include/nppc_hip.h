@@ -123,7 +123,7 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
 /* fused backward of a TCNBlock's middle (causal_conv.py:98-106 in reverse: GroupNorm-2, PReLU-2, depthwise dilated conv,
  * GroupNorm-1, PReLU-1): dA = gradient of GN2's output -> dpre1 = gradient of conv1x1's output, every parameter gradient of
  * those stages and the conv1x1 bias gradient, in ONE reduce + ONE apply launch (csrc/tcn_bwd.hip).  y1 / y2: the saved PReLU
- * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][8] fp64 workspace (zeroed by the launcher); part:
+ * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][8] fp64 workspace, ZERO on entry (zero it once after allocation; the call leaves it zero); part:
  * nppc_tcn_mid_bwd_part_elems(B, Cc, Tp, batch, &n) -> n floats of workspace for per-workgroup partial sums (a third, tiny launch adds
  * them to the gradients: no contended global atomics); a2 (nullable) receives GN2(y2), the operand of the sconv weight
  * gradient.  Gradients are ACCUMULATED into their destinations.  colpart (nullable): the tile column sums that

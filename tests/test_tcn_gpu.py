@@ -59,7 +59,7 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv):
     (a2 * dA).sum().backward()
     y1_tm, y2_tm, dA_tm = _tm(y1.detach(), Tp, dt), _tm(y2.detach(), Tp, dt), _tm(dA, Tp, dt)
     st1, st2 = _stats(y1_tm, Tv).cuda(), _stats(y2_tm, Tv).cuda()
-    S = torch.empty(Z, B, 8, dtype=torch.float64, device="cuda")
+    S = torch.zeros(Z, B, 8, dtype=torch.float64, device="cuda")      # zero on entry; every call leaves it zero
     part = torch.empty(H.mid_bwd_part_elems(B, C, Tp, Z), device="cuda")
     flat = lambda t: t.float().contiguous().cuda()
     sP = 4096                                                    # parameter stride between branches (elements)
