@@ -11,6 +11,7 @@
 // for the batch statistics.  The transposed convolution (input gradient) is the same kernel on flipped/transposed
 // packed weights; the weight gradient is nine row-shifted TN GEMMs (tcn.hip) or the exact-f32 kernel below.
 // The concatenations are channel slices of one buffer (producers write with a channel offset).
+#include <algorithm>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -634,6 +635,270 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, long
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ thin convolutions
+// The two ends of the U-Net are memory-bound products that the MFMA kernels above compute 32-64 channels wide:
+//   first layer   conv3x3(1 or 2 -> 64)  (unet.py:247-262 `inc`, tmp_utils.py:8-37): 18 MACs per output, 128 B written per pixel
+//   last layer    conv1x1(64 -> 1 or K)  (`outc`): 128 B read per pixel
+// At C3 they took 2.6 of the 20 ms of convolution time (4-13 TFLOP/s).  Direct kernels: one pass over the wide tensor,
+// fp32 accumulation, weights (fp32, torch layout, unpacked) in LDS.
+
+// raw[p][co] = bias[co] + sum_{tap, ci < CIN} X[p + off(tap)][ci] * w[co][ci][tap], interior pixels only; optional folded
+// eval-BatchNorm + LeakyReLU like the MFMA kernels.  Thread = (pixel, 8 consecutive output channels): 16-byte stores.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_thin_fwd_kernel(const T* __restrict__ A, long lda, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float slope, T* __restrict__ C,
+                                                               long ldc, long P, int H, int W, int Cout) {
+  // a thread owns FOUR consecutive haloed pixel rows p0 .. p0+3 (neighbours along x) and 8 output channels: the 18 input
+  // columns (3 kernel rows x 6 positions) are loaded once for the four, and each weight vector read from LDS serves
+  // four pixels -- one pixel per thread was bound by the 18-36 LDS weight reads and 9-18 two-byte loads per pixel
+  extern __shared__ float wl[];                        // [9 * CIN][Cout]
+  for (int i = threadIdx.x; i < 9 * CIN * Cout; i += 256) {
+    const int co = i % Cout, k = i / Cout, tap = k / CIN, ci = k % CIN;
+    wl[i] = w[((long)co * CIN + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int chunks = Cout / 8, ppb = 256 / chunks;
+  const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;
+  if (pl >= ppb) return;
+  float bv[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bv[j] = bias ? bias[ch * 8 + j] : 0.f;
+    sc[j] = scale ? scale[ch * 8 + j] : 1.f;
+    sh[j] = scale ? shift[ch * 8 + j] : 0.f;
+  }
+  for (long p0 = ((long)blockIdx.x * ppb + pl) * 4; p0 < P; p0 += (long)gridDim.x * ppb * 4) {
+    bool in[4];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { in[u] = interior(p0 + u, P, H, W); any |= in[u]; }
+    if (!any) continue;
+    float x[3][6][CIN];                                // rows dy = -1..1, positions p0-1 .. p0+4 (guard rows make every read legal)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) x[r][c][ci] = to_f32<T>(A[(p0 + (long)(r - 1) * (W + 2) + (c - 1)) * lda + ci]);
+    float acc[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[u][j] = bv[j];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (tap * CIN + ci) * Cout + ch * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (tap * CIN + ci) * Cout + ch * 8 + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xv = x[tap / 3][u + tap % 3][ci];
+          acc[u][0] += xv * w0.x; acc[u][1] += xv * w0.y; acc[u][2] += xv * w0.z; acc[u][3] += xv * w0.w;
+          acc[u][4] += xv * w1.x; acc[u][5] += xv * w1.y; acc[u][6] += xv * w1.z; acc[u][7] += xv * w1.w;
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!in[u]) continue;
+      if (scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = acc[u][j] * sc[j] + sh[j];
+          acc[u][j] = v > 0.f ? v : slope * v;
+        }
+      }
+      store8<T>(C + (p0 + u) * ldc + ch * 8, acc[u]);
+    }
+  }
+}
+
+// part[block][co][ci][tap] = sum over the block's pixel rows of dY[p][co] * X[p + off(tap)][ci]   (all haloed rows: dY's halo
+// is zero).  Thread = (pixel group, kernel row dy, 8 consecutive output channels): one 16-byte dY read and 3 x CIN input
+// values per pixel, 24 x CIN accumulators.  (A first version with one channel PAIR per thread issued 19 loads per thread and
+// pixel -- 32 lanes fetching the same 18 input values -- and was address-bound: slower than the MFMA path it replaced.)
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_thin_wgrad_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+                                                                 long ldx, float* __restrict__ part, long P, int W, int Cout) {
+  extern __shared__ float red[];                       // [groups][Cout][9 * CIN]
+  const int chunks = Cout / 8, tpp = 3 * chunks, groups = 256 / tpp;
+  const int ch = threadIdx.x % chunks, tg = (threadIdx.x / chunks) % 3, pg = threadIdx.x / tpp;
+  const int n = Cout * 9 * CIN;
+  float acc[3][CIN][8];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][ci][j] = 0.f;
+  if (pg < groups) {
+    // two pixel rows per iteration (loads of both in flight before the FMAs: the loop is latency-bound otherwise); the second
+    // one is clamped to the last row and weighted 0 past the end
+    const long stride = (long)gridDim.x * groups;
+    for (long p = (long)blockIdx.x * groups + pg; p < P; p += 2 * stride) {
+      const long p2 = p + stride < P ? p + stride : P - 1;
+      const float m2 = p + stride < P ? 1.f : 0.f;
+      float d[8], e[8];
+      load8<T>(dY + p * lddy + ch * 8, d);
+      load8<T>(dY + p2 * lddy + ch * 8, e);
+      const T* xp = X + (p + (long)(tg - 1) * (W + 2) - 1) * ldx;
+      const T* xq = X + (p2 + (long)(tg - 1) * (W + 2) - 1) * ldx;
+      float xa[3][CIN], xb[3][CIN];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          xa[t][ci] = to_f32<T>(xp[t * ldx + ci]);
+          xb[t][ci] = to_f32<T>(xq[t * ldx + ci]) * m2;
+        }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[t][ci][j] += d[j] * xa[t][ci] + e[j] * xb[t][ci];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(size_t)pg * n + ((ch * 8 + j) * CIN + ci) * 9 + 3 * tg + t] = acc[t][ci][j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {          // i = (co * CIN + ci) * 9 + tap: torch layout [co][ci][tap]
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += red[(size_t)g * n + i];
+    part[(size_t)blockIdx.x * n + i] = s;
+  }
+}
+
+// dW[i] = sum_blocks part[b][i]: 64 columns x 16 slices of the blocks per workgroup (one thread per column walking all the
+// blocks took longer than the pass over the activations)
+__global__ __launch_bounds__(1024) void thin_wgrad_finish_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ dW) {
+  __shared__ double red[16][64];
+  const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  double a = 0.0;
+  if (i < n) {
+#pragma unroll 8
+    for (int b = slice; b < nblocks; b += 16) a += (double)part[(size_t)b * n + i];
+  }
+  red[slice][col] = a;
+  __syncthreads();
+  if (slice == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a += red[k][col];
+    dW[i] = (float)a;
+  }
+}
+
+// out[p][k] = bias[k] + sum_ci X[p][ci] * w[k][ci],  k < K <= 8, Cin = 64: 8 lanes per pixel (16 bytes of the row each),
+// partial dot products reduced over the 8 lanes.  Interior pixels only, columns K..ld-1 untouched.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_thin_fwd_kernel(const T* __restrict__ X, long ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ C, long ldc, long P,
+                                                               int H, int W, int K) {
+  __shared__ float wl[8 * 64];
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) wl[i] = i < K * 64 ? w[i] : 0.f;
+  __syncthreads();
+  const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  for (long p = (long)blockIdx.x * 32 + pl; p < P; p += (long)gridDim.x * 32) {
+    const bool in = interior(p, P, H, W);               // (whole 8-lane groups agree: no divergence inside a shuffle group)
+    float xv[8];
+    if (in) load8<T>(X + p * ldx + ch * 8, xv);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = 0.f;
+    }
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += xv[j] * wl[k * 64 + ch * 8 + j];
+      a += __shfl_xor(a, 1);
+      a += __shfl_xor(a, 2);
+      a += __shfl_xor(a, 4);
+      acc[k] = a;
+    }
+    if (in && ch < K) {
+      float v = acc[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v = ch == k ? acc[k] : v;
+      C[p * ldc + ch] = from_f32<T>(v + (bias ? bias[ch] : 0.f));
+    }
+  }
+}
+
+// dX[p][ci] = sum_{k < K} dY[p][k] * w[k][ci]   (Cin = 64; interior pixels; dY's halo is zero anyway)
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_thin_bwd_data_kernel(const T* __restrict__ dY, long lddy, const float* __restrict__ w,
+                                                                    T* __restrict__ dX, long lddx, long P, int H, int W, int K) {
+  __shared__ float wl[8 * 64];
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) wl[i] = i < K * 64 ? w[i] : 0.f;
+  __syncthreads();
+  const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  for (long p = (long)blockIdx.x * 32 + pl; p < P; p += (long)gridDim.x * 32) {
+    if (!interior(p, P, H, W)) continue;
+    float d[8];
+    load8<T>(dY + p * lddy, d);                         // lddy >= 8: columns K..7 are zero in the gradient buffer or masked here
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = k < K ? d[k] : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += d[k] * wl[k * 64 + ch * 8 + j];
+      acc[j] = a;
+    }
+    store8<T>(dX + p * lddx + ch * 8, acc);
+  }
+}
+
+// part[block][k][ci] = sum over the block's rows of dY[p][k] * X[p][ci]   (K <= 8, Cin = 64; all haloed rows)
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_thin_wgrad_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+                                                                 long ldx, float* __restrict__ part, long P, int K) {
+  __shared__ float red[32][8 * 64 / 8 + 1][8];          // [pixel lane][k * 8 + chunk][8 channels of the chunk] (padded)
+  const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  float acc[8][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  const long stride = (long)gridDim.x * 32;
+  for (long p = (long)blockIdx.x * 32 + pl; p < P; p += 2 * stride) {     // two rows in flight per thread (latency-bound otherwise)
+    const long p2 = p + stride < P ? p + stride : P - 1;
+    const float m2 = p + stride < P ? 1.f : 0.f;
+    float xv[8], yv[8], d[8], e[8];
+    load8<T>(X + p * ldx + ch * 8, xv);
+    load8<T>(X + p2 * ldx + ch * 8, yv);
+    load8<T>(dY + p * lddy, d);                        // the K <= 8 gradient columns of the row: one 16-byte read (lddy >= 8)
+    load8<T>(dY + p2 * lddy, e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float dk = k < K ? d[k] : 0.f, ek = k < K ? e[k] * m2 : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] += dk * xv[j] + ek * yv[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pl][k * 8 + ch][j] = acc[k][j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * 64; i += 256) {      // i = k * 64 + ci
+    const int k = i / 64, ci = i % 64;
+    float s = 0.f;
+    for (int g = 0; g < 32; ++g) s += red[g][k * 8 + ci / 8][ci % 8];
+    part[(size_t)blockIdx.x * (K * 64) + i] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ boundary maps
 // log-magnitude of a [B,2,F,T] STFT pair + fp64 sum / sum of squares (utils.py:273-306)
 __global__ __launch_bounds__(256) void logmag_kernel(const float* __restrict__ spec, float* __restrict__ out, long FT, long total,
@@ -780,6 +1045,87 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
   }
   dim3 grid(ceil_div(g.P, 128), Np / 64);
   LAUNCH_T(prec, conv_kernel, grid, g);
+  return NPPC_OK;
+}
+
+/* thin ends of the U-Net (csrc/unet.hip "thin convolutions"): w are the fp32 parameter tensors in torch layout, no packing.
+ * part: workspace of nppc_conv_thin_part_elems() floats. */
+int nppc_conv_thin_part_elems(long* n) {
+  if (!n) return NPPC_EBADARG;
+  *n = 1024L * 64 * 9 * 2;       // 1024 blocks x the largest gradient tensor (64 x 2 x 3 x 3), or 2048 x the 1x1 head's 8 x 64
+  return NPPC_OK;
+}
+
+int nppc_conv3x3_thin_fwd(int prec, const void* A, long lda, const float* w, const float* bias, const float* scale,
+                          const float* shift, float slope, void* C, long ldc, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!A || !w || !C || B <= 0 || H <= 0 || W <= 0 || (scale && !shift)) return NPPC_EBADARG;
+  if (Cin < 1 || Cin > 2 || Cout % 8 || Cout > 64 || 256 % (Cout / 8)) return NPPC_EUNSUPPORTED;
+  const long P = (long)B * (H + 2) * (W + 2);
+  if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
+  const int ppb = 256 / (Cout / 8);
+  const dim3 grid((unsigned)std::min<long>(ceil_div(P, (long)ppb * 4), 256L * 16));
+  const size_t sm = sizeof(float) * 9 * Cin * Cout;
+  hipStream_t st = (hipStream_t)stream;
+#define THIN_FWD(TT, CI) hipLaunchKernelGGL((conv3x3_thin_fwd_kernel<TT, CI>), grid, dim3(256), sm, st, (const TT*)A, lda, w, bias, scale, shift, slope, (TT*)C, ldc, P, H, W, Cout)
+  if (prec == NPPC_PREC_BF16) { if (Cin == 1) THIN_FWD(bf16_t, 1); else THIN_FWD(bf16_t, 2); }
+  else if (prec == NPPC_PREC_F32) { if (Cin == 1) THIN_FWD(float, 1); else THIN_FWD(float, 2); }
+  else return NPPC_EBADARG;
+#undef THIN_FWD
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_conv3x3_thin_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* part, float* dW, int B, int H,
+                            int W, int Cin, int Cout, void* stream) {
+  if (!dY || !X || !part || !dW || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
+  if (Cin < 1 || Cin > 2 || Cout % 8 || Cout > 64) return NPPC_EUNSUPPORTED;
+  const long P = (long)B * (H + 2) * (W + 2);
+  const int groups = 256 / (3 * (Cout / 8)), n = Cout * 9 * Cin;
+  const int nblocks = (int)std::min<long>(ceil_div(P, (long)groups * 64), 1024L);
+  const size_t sm = sizeof(float) * groups * n;
+  hipStream_t st = (hipStream_t)stream;
+#define THIN_WG(TT, CI) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<TT, CI>), dim3(nblocks), dim3(256), sm, st, (const TT*)dY, lddy, (const TT*)X, ldx, part, P, W, Cout)
+  if (prec == NPPC_PREC_BF16) { if (Cin == 1) THIN_WG(bf16_t, 1); else THIN_WG(bf16_t, 2); }
+  else if (prec == NPPC_PREC_F32) { if (Cin == 1) THIN_WG(float, 1); else THIN_WG(float, 2); }
+  else return NPPC_EBADARG;
+#undef THIN_WG
+  NPPC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, st, part, nblocks, n, dW);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_conv1x1_thin_fwd(int prec, const void* X, long ldx, const float* w, const float* bias, void* C, long ldc, int B, int H,
+                          int W, int Cin, int K, void* stream) {
+  if (!X || !w || !C || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
+  if (Cin != 64 || K < 1 || K > 8 || ldx % 8) return NPPC_EUNSUPPORTED;
+  const long P = (long)B * (H + 2) * (W + 2);
+  if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
+  const dim3 grid((unsigned)std::min<long>(ceil_div(P, 32), 256L * 16));
+  LAUNCH_T(prec, conv1x1_thin_fwd_kernel, grid, (const TT*)X, ldx, w, bias, (TT*)C, ldc, P, H, W, K);
+  return NPPC_OK;
+}
+
+int nppc_conv1x1_thin_bwd_data(int prec, const void* dY, long lddy, const float* w, void* dX, long lddx, int B, int H, int W,
+                               int Cin, int K, void* stream) {
+  if (!dY || !w || !dX || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
+  if (Cin != 64 || K < 1 || K > 8 || lddx % 8 || lddy % 8) return NPPC_EUNSUPPORTED;
+  const long P = (long)B * (H + 2) * (W + 2);
+  if (P >= (1L << 31)) return NPPC_EUNSUPPORTED;
+  const dim3 grid((unsigned)std::min<long>(ceil_div(P, 32), 256L * 16));
+  LAUNCH_T(prec, conv1x1_thin_bwd_data_kernel, grid, (const TT*)dY, lddy, w, (TT*)dX, lddx, P, H, W, K);
+  return NPPC_OK;
+}
+
+int nppc_conv1x1_thin_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* part, float* dW, int B, int H,
+                            int W, int Cin, int K, void* stream) {
+  if (!dY || !X || !part || !dW || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
+  if (Cin != 64 || K < 1 || K > 8 || ldx % 8 || lddy % 8) return NPPC_EUNSUPPORTED;
+  const long P = (long)B * (H + 2) * (W + 2);
+  const int nblocks = (int)std::min<long>(ceil_div(P, 32L * 16), 2048L);
+  LAUNCH_T(prec, conv1x1_thin_wgrad_kernel, dim3(nblocks), (const TT*)dY, lddy, (const TT*)X, ldx, part, P, K);
+  hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3(ceil_div(K * 64, 64)), dim3(1024), 0, (hipStream_t)stream, part, nblocks, K * 64, dW);
+  NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
 

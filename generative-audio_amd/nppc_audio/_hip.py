@@ -68,6 +68,12 @@ def mid_bwd_part_elems(B, C, Tp, batch):
     return n.value
 
 
+def conv_thin_part_elems():
+    n = c_l()
+    call("nppc_conv_thin_part_elems", ctypes.byref(n))
+    return n.value
+
+
 def dtype_of(prec):
     return torch.bfloat16 if prec == PREC_BF16 else torch.float32
 
@@ -169,6 +175,12 @@ SIGS = {
     "nppc_conv_pack": [I, P, P, P, I, I, I, I, I, I, I, P],
     "nppc_conv_fwd": [I, P, L, P, P, L, P, P, P, F, I, I, I, I, I, I, I, P],
     "nppc_conv_wgrad": [I, P, L, P, L, P, I, I, I, I, I, I, I, P],
+    "nppc_conv_thin_part_elems": [PL],
+    "nppc_conv3x3_thin_fwd": [I, P, L, P, P, P, P, F, P, L, I, I, I, I, I, P],
+    "nppc_conv3x3_thin_wgrad": [I, P, L, P, L, P, P, I, I, I, I, I, P],
+    "nppc_conv1x1_thin_fwd": [I, P, L, P, P, P, L, I, I, I, I, I, P],
+    "nppc_conv1x1_thin_bwd_data": [I, P, L, P, P, L, I, I, I, I, I, P],
+    "nppc_conv1x1_thin_wgrad": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "nppc_conv_wgrad_transposed": [I, I],
     "nppc_conv_wgrad_reduce": [I, P, I, I, I, P, I, I, I, P],
     "nppc_bn_stats": [I, P, L, L, I, P, P],

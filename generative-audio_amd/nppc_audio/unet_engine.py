@@ -6,6 +6,8 @@ resolution level and the launch order of forward and backward.  The frozen resto
 BatchNorm folded into the convolution epilogue (eval mode); the direction U-Net runs in train mode
 (batch statistics, running-buffer update) and keeps what its backward needs.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -24,6 +26,7 @@ OUT_LD = 64         # so is the K-channel output of the 1x1 convolution
 DROP_BLOCKS = ("down3", "down4", "up1", "up2")    # double_convs that end in nn.Dropout (unet.py:254-257)
 
 
+THIN = os.environ.get("NPPC_UNET_THIN", "1") != "0"      # direct kernels for the first (1-2 channel) and last (1x1, K <= 8) convolutions
 PROFILE = None      # bench hook: list of (kind, algorithmic flops, start event, end event)
 
 
@@ -144,6 +147,7 @@ class UNetEngine:
         self.ksplit = [int(min(64, max(1, p // 1024))) for p in self.P]   # 64 slices x 9 taps already fill the chip; more only costs reduction traffic
         self.ksplit = [k // 8 * 8 if k >= 8 else k for k in self.ksplit]     # multiples of 8: XCD-aware tile order
         self.slab = None
+        self._thin_part = None
         self.st = torch.zeros(2 * 1024, dtype=torch.float64, device=self.dev)
 
     def buf(self, tag, level, ld):
@@ -164,6 +168,17 @@ class UNetEngine:
         if ks == 3 and cinp != ldx:
             raise RuntimeError(f"{name}: input row width {ldx} != packed K {cinp}")
         ss = self.ss[name] if fold else None
+        if THIN and ks == 3 and cin <= 2 and cout <= 64 and cout % 8 == 0:
+            # first layer: memory-bound, 18 MACs per output -- direct kernel on the fp32 parameter tensor (csrc/unet.hip)
+            with _timed("conv_fwd", 2.0 * B * h * w * cin * cout * ks * ks):
+                H.call("nppc_conv3x3_thin_fwd", self.prec, x, ldx, self.p(name + ".weight"), self.p(name + ".bias"), ss,
+                       ss[cout:] if fold else None, LEAK, y, ldy, B, h, w, cin, cout, H.stream())
+            return
+        if THIN and ks == 1 and cin == 64 and cout <= 8 and not fold:
+            with _timed("conv_fwd", 2.0 * B * h * w * cin * cout * ks * ks):
+                H.call("nppc_conv1x1_thin_fwd", self.prec, x, ldx, self.p(name + ".weight"), self.p(name + ".bias"), y, ldy, B, h, w,
+                       cin, cout, H.stream())
+            return
         with _timed("conv_fwd", 2.0 * B * h * w * cin * cout * ks * ks):
             H.call("nppc_conv_fwd", self.prec, x, ldx, self.wf[name], y, ldy, self.p(name + ".bias"),
                    ss, ss[cout:] if fold else None, LEAK, B, h, w, cinp, cout, np_, ks, H.stream())
@@ -301,8 +316,16 @@ class UNetEngine:
         h, w = self.lv[level]
         M, N = lddy, ldx
         S = self.ksplit[level]
-        slabs = self._slabs(ks * ks * S * rup(M, 128) * N)
         s = H.stream()
+        thin3, thin1 = THIN and ks == 3 and cin <= 2 and cout <= 64 and cout % 8 == 0, THIN and ks == 1 and cin == 64 and cout <= 8
+        if thin3 or thin1:
+            if self._thin_part is None:
+                self._thin_part = torch.empty(H.conv_thin_part_elems(), dtype=torch.float32, device=self.dev)
+            with _timed("conv_wgrad", 2.0 * B * h * w * cin * cout * ks * ks):
+                H.call("nppc_conv3x3_thin_wgrad" if thin3 else "nppc_conv1x1_thin_wgrad", self.prec, dy, lddy, x, ldx, self._thin_part,
+                       self.g(name + ".weight"), B, h, w, cin, cout, s)
+            return
+        slabs = self._slabs(ks * ks * S * rup(M, 128) * N)
         with _timed("conv_wgrad", 2.0 * B * h * w * cin * cout * ks * ks):
             H.call("nppc_conv_wgrad", self.prec, dy, lddy, x, ldx, slabs, M, N, B, h, w, ks, S, s)
             H.call("nppc_conv_wgrad_reduce", self.prec, slabs, S, M, N, self.g(name + ".weight"), cout, cin, ks, s)
@@ -312,6 +335,11 @@ class UNetEngine:
         B = self.geo[0]
         h, w = self.lv[level]
         cinp, np_ = self._dims(name, cin, cout)
+        if THIN and ks == 1 and cin == 64 and cout <= 8:
+            with _timed("conv_bwd_data", 2.0 * B * h * w * cin * cout * ks * ks):
+                H.call("nppc_conv1x1_thin_bwd_data", self.prec, dy, lddy, self.p(name + ".weight"), dx, lddx, B, h, w, cin, cout,
+                       H.stream())
+            return
         with _timed("conv_bwd_data", 2.0 * B * h * w * cin * cout * ks * ks):
             H.call("nppc_conv_fwd", self.prec, dy, lddy, self.wb[name], dx, lddx, None, None, None, LEAK, B, h, w, np_, cin,
                    cinp, ks, H.stream())

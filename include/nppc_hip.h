@@ -362,6 +362,22 @@ int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx
 int nppc_conv_wgrad_transposed(int M, int N);
 int nppc_conv_wgrad_reduce(int prec, const float* slabs, int ksplit, int M, int N, float* dW, int Cout, int Cin, int ksize,
                            void* stream);
+/* The thin ends of the U-Net (unet.py:247-262 `inc`: conv3x3 from 1-2 channels; `outc`: conv1x1 64 -> K <= 8; tmp_utils.py:8-37):
+ * memory-bound products that the MFMA path computes 32-64 channels wide.  Direct kernels, same haloed NHWC tensors and the same
+ * results as nppc_conv_fwd / nppc_conv_wgrad + _reduce / the transposed nppc_conv_fwd, but w / dW are the fp32 parameter
+ * tensors in torch layout ([Cout][Cin][kh][kw], no packing) and the products accumulate in fp32.  part: workspace of
+ * nppc_conv_thin_part_elems floats.  3x3: Cin 1 or 2, Cout % 8 == 0, <= 64; 1x1: Cin == 64, K <= 8. */
+int nppc_conv_thin_part_elems(long* n);
+int nppc_conv3x3_thin_fwd(int prec, const void* A, long lda, const float* w, const float* bias, const float* scale,
+                          const float* shift, float slope, void* C, long ldc, int B, int H, int W, int Cin, int Cout, void* stream);
+int nppc_conv3x3_thin_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* part, float* dW, int B, int H,
+                            int W, int Cin, int Cout, void* stream);
+int nppc_conv1x1_thin_fwd(int prec, const void* X, long ldx, const float* w, const float* bias, void* C, long ldc, int B, int H,
+                          int W, int Cin, int K, void* stream);
+int nppc_conv1x1_thin_bwd_data(int prec, const void* dY, long lddy, const float* w, void* dX, long lddx, int B, int H, int W,
+                               int Cin, int K, void* stream);
+int nppc_conv1x1_thin_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* part, float* dW, int B, int H,
+                            int W, int Cin, int K, void* stream);
 int nppc_bn_stats(int prec, const void* X, long ld, long P, int C, double* st, void* stream);
 int nppc_bn_finalize(const double* st, const float* gamma, const float* beta, float* rmean, float* rvar, float* ss, int C,
                      double n, float eps, float momentum, int train, void* stream);

@@ -105,6 +105,72 @@ def test_conv_forward_input_gradient_weight_gradient(pname, prec, dtype, tol, B,
 
 
 @pytest.mark.parametrize("pname,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 9, 13, 1), (3, 6, 37, 2)])
+def test_thin_first_convolution_matches_conv2d(pname, prec, dtype, tol, B, H, W, Cin):
+    """conv3x3(1 or 2 -> 64) on the direct kernels (tmp_utils.py:8-37 `inc`): forward, folded eval-BatchNorm epilogue,
+    weight gradient; the activations are rounded to the storage dtype, the weights stay fp32 (unpacked parameter tensor)"""
+    from nppc_audio import _hip as Hh
+    Cout, ld = 64, 32
+    g = torch.Generator().manual_seed(11 * B + Cin)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 3.0
+    b = torch.randn(Cout, generator=g) * 0.1
+    s = Hh.stream()
+    X = Halo(B, H, W, ld, dtype).put(x)
+    Y = Halo(B, H, W, Cout, dtype)
+    Hh.call("nppc_conv3x3_thin_fwd", prec, X.t, ld, w.cuda(), b.cuda(), None, None, 0.2, Y.t, Cout, B, H, W, Cin, Cout, s)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel(Y.get(Cout), ref) < tol
+    assert Y.halo_is_zero()
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    Y2 = Halo(B, H, W, Cout, dtype)
+    Hh.call("nppc_conv3x3_thin_fwd", prec, X.t, ld, w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), 0.2, Y2.t, Cout, B, H, W, Cin, Cout, s)
+    assert rel(Y2.get(Cout), F.leaky_relu(ref * sc[None, :, None, None] + sh[None, :, None, None], 0.2)) < tol
+    dy = q(torch.randn(B, Cout, H, W, generator=g), dtype)
+    DY = Halo(B, H, W, Cout, dtype).put(dy)
+    part = torch.empty(Hh.conv_thin_part_elems(), dtype=torch.float32, device="cuda")
+    dW = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device="cuda")
+    Hh.call("nppc_conv3x3_thin_wgrad", prec, DY.t, Cout, X.t, ld, part, dW, B, H, W, Cin, Cout, s)
+    torch.cuda.synchronize()
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, padding=1).backward(dy)
+    assert rel(dW.cpu(), wr.grad) < (tol if pname == "fp32" else 2e-3)
+
+
+@pytest.mark.parametrize("pname,prec,dtype,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,K", [(2, 9, 13, 1), (3, 6, 37, 5), (1, 4, 9, 8)])
+def test_thin_output_convolution_matches_conv2d(pname, prec, dtype, tol, B, H, W, K):
+    """conv1x1(64 -> K <= 8) (`outc`, unet.py:262): forward, input gradient, weight gradient on the direct kernels"""
+    from nppc_audio import _hip as Hh
+    Cin, ld = 64, 64
+    g = torch.Generator().manual_seed(7 * B + K)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(K, Cin, 1, 1, generator=g) / 8.0
+    b = torch.randn(K, generator=g) * 0.1
+    s = Hh.stream()
+    X = Halo(B, H, W, Cin, dtype).put(x)
+    Y = Halo(B, H, W, ld, dtype)
+    Hh.call("nppc_conv1x1_thin_fwd", prec, X.t, Cin, w.cuda(), b.cuda(), Y.t, ld, B, H, W, Cin, K, s)
+    torch.cuda.synchronize()
+    assert rel(Y.get(K), F.conv2d(x, w, b)) < tol
+    assert Y.halo_is_zero() and float(Y.get(ld - K, K).abs().max()) == 0.0
+    dy = q(torch.randn(B, K, H, W, generator=g), dtype)
+    DY = Halo(B, H, W, ld, dtype).put(dy)
+    DX = Halo(B, H, W, Cin, dtype)
+    Hh.call("nppc_conv1x1_thin_bwd_data", prec, DY.t, ld, w.cuda(), DX.t, Cin, B, H, W, Cin, K, s)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None).backward(dy)
+    assert rel(DX.get(Cin), xr.grad) < tol
+    assert DX.halo_is_zero()
+    part = torch.empty(Hh.conv_thin_part_elems(), dtype=torch.float32, device="cuda")
+    dW = torch.empty(K, Cin, 1, 1, dtype=torch.float32, device="cuda")
+    Hh.call("nppc_conv1x1_thin_wgrad", prec, DY.t, ld, X.t, Cin, part, dW, B, H, W, Cin, K, s)
+    torch.cuda.synchronize()
+    assert rel(dW.cpu(), wr.grad) < (tol if pname == "fp32" else 2e-3)
+
+
+@pytest.mark.parametrize("pname,prec,dtype,tol", PRECS)
 def test_batchnorm_leakyrelu_forward_backward(pname, prec, dtype, tol):
     from nppc_audio import _hip as Hh
     B, H, W, C = 3, 7, 11, 64
