@@ -58,13 +58,15 @@ def build_model(c, precision, tmp_path):
 
 _FP64_ORACLE = {}
 W_MAT_BF16_TOL = 1.5e-1
+PRELU_VECTOR_TOL = 0.2     # the 8 PReLU slopes of a kind as one tensor: error / max |grad| over the 8 (bf16 mode; measured 0.145 / 0.069)
 
 
 def bf16_grad_tol(n):
     """bf16 mode, error / max|grad| vs the fp64 oracle for the well-conditioned tensors (table in DESIGN.md section 2):
     0.2 for weight / bias / GroupNorm tensors (measured worst: attention 0.155, TCN 1x1 / depthwise / norm 0.11, sub-band
-    LSTM + head 0.042); 0.6 for the PReLU slopes, single scalars that are sums over every element of a [B, 512, T'] tensor
-    with heavy cancellation (measured worst 0.49)"""
+    LSTM + head 0.042); 0.6 for the PReLU slopes taken one by one: single scalars of 1e-7 .. 1e-6 that are sums over every
+    element of a [B, 512, T'] tensor with heavy cancellation (measured worst 0.50: -1.23e-7 vs -0.61e-7, an absolute error of
+    6e-8 next to slopes of 1.2e-6) -- as ONE tensor per kind they are held to PRELU_VECTOR_TOL like every other family"""
     return 0.6 if ".prelu" in n else 0.2
 
 
@@ -162,6 +164,17 @@ def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
         for k, v in fam.items():
             record_err("bf16_grad." + k, v, bf16_grad_tol("x" + (".prelu" if "prelu" in k else "")))
         record_err("bf16_grad.cos_deficit", 1.0 - cos, 0.01)
+        # The PReLU slopes are single scalars (sums over every element of a [B, 512, T'] tensor): "error / max|grad| of the
+        # tensor" divides by the scalar itself, so a slope whose gradient nearly cancels shows a large ratio at a small
+        # absolute error.  Held as well the way a channel vector is: the 8 slopes of a kind (prelu1 / prelu2 of the 8 TCN
+        # blocks of the branch) as ONE tensor, error / max |grad| over the 8.
+        for kind in ("prelu1", "prelu2"):
+            sl = [n for n in well if n.endswith(kind + ".weight")]
+            rv = np.array([float(ref[n].reshape(-1)[0]) for n in sl])
+            gv = np.array([float(got[n].grad.double().cpu().reshape(-1)[0]) for n in sl])
+            print(name, kind, "slope gradients (fp64 oracle | bf16 path):", [f"{a:+.3e}|{b:+.3e}" for a, b in zip(rv, gv)])
+            record_err(f"bf16_grad.tcn.{kind}_as_one_vector", float(np.abs(gv - rv).max() / np.abs(rv).max()), PRELU_VECTOR_TOL)
+            assert np.abs(gv - rv).max() <= PRELU_VECTOR_TOL * np.abs(rv).max(), (kind, rv, gv)
         bad = {n: worst[n] for n in well if worst[n] > bf16_grad_tol(n)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
         assert cos > 0.99 and abs(np.sqrt(nn_g / nn_r) - 1) < 0.05
