@@ -219,6 +219,7 @@ def hbm_family_bytes(B, L, T, K, n_params, act_bytes, g_pc=2):
 
 
 ROCPROF_NAME = {   # bench label prefix -> substring of the rocprofv3 kernel name (template arguments included)
+    "lstm2_bwd_coop_ksplit_g4": "lstm2_coop_bwd4_kernel",
     "lstm2_bwd_coop_ksplit": "lstm2_coop_bwd2_kernel",
     "lstm2_fwd_coop_g2[N=8224": "2, 5, 64, false",
     "lstm2_fwd_coop_g2_train[N=4096": "2, 2, 64, true",

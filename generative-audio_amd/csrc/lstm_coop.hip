@@ -15,6 +15,7 @@
 // only: the counter survives later launches and is cleared by the caller alone (ops_lstm.clear_coop_timeouts), so a host
 // check at any later point (trainer log interval, end of bench) still sees a time-out of ANY earlier launch.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -930,7 +931,11 @@ __device__ __forceinline__ void c2_wait(int m, bf16x8& x) {
 template <int NS, int XR /* partner-partials round of the own-tile pass, < 0: none */, int POPS, typename Pre, typename Side, typename Post>
 __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, const unsigned char* wbase /* (cu, wave) */,
                                         int lane, int RS, int s0, int s1, Pre&& pre, Side&& side, Post&& post) {
+#ifdef C2_DIAG_HALFK
+  constexpr int DEPTH = C2_DEPTH, D = DEPTH - 1, NK = C2_NKK / 2;  // diagnostic: half the k-steps (garbage results; what half the fragment stream would buy)
+#else
   constexpr int DEPTH = C2_DEPTH, D = DEPTH - 1, NK = C2_NKK;      // D = prefetch distance in k-steps
+#endif
   static_assert(DEPTH >= 2 && D <= 8 && (XR < 0 || 4 * XR + D < NK), "ring depth / partner round out of the wait model's range");
   bf16x8 b[DEPTH][2];
   int lane16 = lane * 16;
@@ -1396,6 +1401,493 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
 #endif
 }
 
+// =====================================================================================================
+// K-split backward on FOUR-CU clusters (round 3): 64 sequences per cluster, CU `cu` owns hidden units [96 cu, 96 cu + 96)
+// of both layers.  Same data flow as lstm2_coop_bwd2_kernel -- every CU multiplies ITS OWN gate-gradient quarter
+// [64][384] with the weight rows of its own units and all output columns, keeps the partial sums of the output tiles it
+// owns and ships the rest as bf16, accumulator to accumulator, to the same wave of the owner -- but a CU streams a
+// QUARTER of the weight fragments per step for 64 rows (0.93 MB instead of 1.87 MB for 32): the launches are bound by
+// the fragment stream, and halving the k-steps of the pair kernel (a diagnostic build) took 7.4 -> 5.5 ms.
+// Per layer and step: three partner passes (tiles of owner cu+1, cu+2, cu+3: shipped after each pass, flagged per wave
+// in front of the next one), then the own pass, whose accumulators start from the first partner's partials; the second
+// partner's arrive during the own pass, the third's -- shipped one pass earlier -- are waited for behind it.
+//   layer 2 output tiles of owner O: wave w < 6 -> d h1 columns 96 O + 16 w, wave w >= 6 -> d h2_{t-1} columns 96 O + 16 (w - 6)
+//   layer 1 output tiles of owner O: wave w < 6 -> d h1_{t-1} columns 96 O + 16 w, wave 6 -> d x columns 16 O .. 16 O + 15
+constexpr int C4_G = 4, C4_MC = 64, C4_HC = 96, C4_KC = 4 * C4_HC, C4_NKK = C4_KC / 32;   // 384 own gate columns = 12 k-steps
+constexpr int C4_FPC = 2 * C4_G * 3 * CB_NW;                // epoch words per cluster: [layer][src cu][shipment][wave]
+constexpr int C4_SLAB = CB_NW * 64 * 32;                    // bytes of one shipment: [wave][lane][32 B] (4 row tiles x 4 values, bf16)
+constexpr long C4_XCH = 2L * 2 * C4_G * 3 * C4_SLAB;        // bytes per cluster: [layer][parity][src cu][shipment]
+constexpr long C4_WFRAG = (long)C4_NKK * C4_G * 1024;       // packed weights of one (cu, wave): [kk][owner][lane][8] bf16
+
+// The four passes of a layer (three partner tiles, then the own tile: 48 k-steps) run as ONE fragment stream -- the ring never
+// restarts cold at a pass boundary and nothing is drained between passes.  Program order per position g = 12 p + k:
+//   side(g)   g = 20, 32, 44: raise the epoch of shipment 0, 1, 2 (1 store, behind a counted wait for the shipment's stores);
+//             g = 24, 36: request the epoch of the partner whose partials are due (1 load); g = 28, 40: its partials (2 loads)
+//   request of fragment g + 3
+//   wait + the four MFMAs of k-step g
+//   tail(g)   g = 11, 23, 35: ship the finished partner tile (2 stores; g = 11 of layer 2 with the fused head: + 2 dY DMAs)
+// Every wait is vmcnt(M), M = operations issued after the one waited for (c2_gemm's rule); this table holds the counts.
+#ifndef C4_DEPTH
+#define C4_DEPTH 8                                          // fragment ring of the four-CU kernel: C4_DEPTH - 1 k-steps (1 KB each) requested ahead
+#endif
+template <int DY, int D /* k-steps requested ahead */>
+struct C4Sched {
+  int before[49];    // vector-memory operations issued before side(pos)
+  int req_seq[48];   // sequence number of the request of fragment g
+  static constexpr int side(int pos) {
+    return (pos == 20 || pos == 32 || pos == 44 || pos == 24 || pos == 36) ? 1 : ((pos == 28 || pos == 40) ? 2 : 0);
+  }
+  static constexpr int tail(int pos) { return pos == 11 ? 2 + DY : ((pos == 23 || pos == 35) ? 2 : 0); }
+  constexpr C4Sched() : before{}, req_seq{} {
+    int c = D;
+    for (int g = 0; g < D; ++g) req_seq[g] = g;
+    for (int pos = 0; pos < 48; ++pos) {
+      before[pos] = c;
+      c += side(pos);
+      if (pos + D < 48) { req_seq[pos + D] = c; c += 1; }
+      c += tail(pos);
+    }
+    before[48] = c;
+  }
+  constexpr int wait_frag(int g) const { return before[g] + side(g) + (g + D < 48 ? 1 : 0) - req_seq[g] - 1; }
+  constexpr int wait_raise(int q) const { return before[12 * q + 20] - before[12 * q + 12]; }   // since the shipment's last store
+  constexpr int wait_flag(int pos_f) const { return before[pos_f + 4] - before[pos_f] - 1; }     // since the epoch request
+};
+
+template <int... I, typename F>
+__device__ __forceinline__ void c4_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void c4_static_for(F&& f) { c4_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// s_waitcnt vmcnt(m) for a compile-time m
+__device__ __forceinline__ void c4_wait_mem(int m) {
+#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (m) {
+    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12) C4_W(13) C4_W(14)
+    C4_W(15) C4_W(16) C4_W(17) C4_W(18) C4_W(19) C4_W(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef C4_W
+}
+__device__ __forceinline__ void c4_wait_reg(int m, unsigned& x) {
+#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x)); break;
+  switch (m) {
+    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); break;
+  }
+#undef C4_W
+}
+// 16 bytes per lane global -> LDS (lds_base + 16 * lane), through inline asm: invisible to the compiler's wait insertion, which
+// would otherwise drain the fragment ring in front of the next LDS read; completion is covered by a later counted wait
+__device__ __forceinline__ void c4_lds_dma16(const void* src_lane, unsigned lds_base /* wave-uniform */) {
+  unsigned keep;
+  const unsigned lb = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(lb) : "memory");
+}
+
+template <bool HEAD>
+__global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd4_kernel(CoopBwd2Args a) {
+  typedef bf16_t T;
+  constexpr int MC = C4_MC, H = CB_H, HC = C4_HC, KX = CB_KX, NT = CB_NT;
+  constexpr int RSA = C4_KC + 8;                            // A tile row stride (elements): own gate columns only
+  constexpr int TPR = NT / MC, UPT = HC / TPR;              // 12 threads per row, 8 units per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Abuf = reinterpret_cast<T*>(smem_raw);                                          // [64][RSA]   own dgates
+  float* dh1buf = reinterpret_cast<float*>(smem_raw + (size_t)MC * RSA * sizeof(T));  // [64][HC]    d h1 (own units)
+  float* dhrec2 = dh1buf + MC * HC;                                                   // [64][HC]    d h2 recurrent
+  float* dxbuf = dhrec2 + MC * HC;                                                    // [64][16]    own d x columns
+  float* dcbuf = dxbuf + MC * 16;                                                     // [2][64][HC] d c carried from step to step
+  T* whs = reinterpret_cast<T*>(dcbuf + 2 * MC * HC);                                 // HEAD: [HC][16] own units' head weights
+  T* dys = whs + HC * 16;                                                             // HEAD: [64][16]  dY rows of one step
+
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4, n_ = n, q_ = q;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int cluster, cu;
+  coop_ids(C4_G, cluster, cu);
+  if (cluster >= a.clusters) return;
+  const long row0 = (long)cluster * MC;
+  const long N = a.N;
+  for (int i = tid; i < 4 * MC * HC + MC * 16; i += NT) dh1buf[i] = 0.f;      // d h1, d h2 rec, d x, d c (both layers)
+  for (int i = tid; i < MC * RSA; i += NT) Abuf[i] = 0;
+  if constexpr (HEAD) {
+    const T* whT = reinterpret_cast<const T*>(a.whT);
+    for (int i = tid; i < HC * 16; i += NT) whs[i] = whT[(size_t)(cu * HC + i / 16) * 32 + (i % 16)];
+  }
+
+  const int prow = tid / TPR;
+  const bool prow_ok = row0 + prow < N;
+  // (d c of the thread's 8 units per layer lives in LDS, not in 16 registers: both layers' saved state is in flight at
+  // the end of a GEMM pass since round 3, and the registers are what that costs)
+  float* dc1 = dcbuf;
+  float* dc2 = dcbuf + MC * HC;
+
+  const T* g1 = reinterpret_cast<const T*>(a.g1);
+  const T* g2 = reinterpret_cast<const T*>(a.g2);
+  const T* c1 = reinterpret_cast<const T*>(a.c1);
+  const T* c2 = reinterpret_cast<const T*>(a.c2);
+  const T* dh2 = reinterpret_cast<const T*>(a.dh2);
+  T* dx = reinterpret_cast<T*>(a.dx);
+  T* dg1T = reinterpret_cast<T*>(a.dg1);
+  T* dg2T = reinterpret_cast<T*>(a.dg2);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(reinterpret_cast<const unsigned char*>(a.xch) + (size_t)cluster * C4_XCH,
+                                              (unsigned)C4_XCH);
+  gu32* flags = (gu32*)(a.flags + (size_t)cluster * C4_FPC);
+  gu32* tmo = (gu32*)(a.flags + (size_t)a.clusters * C4_FPC);
+  const T* a_lane = Abuf + n * RSA + 8 * q;
+  __syncthreads();
+
+  // Thread -> data: 12 threads per row; thread (prow, tc) owns the four 16-byte chunks c_j = tc + 12 j (j = 0..3) of the
+  // row's own-unit gate block, i.e. units 2 c_j, 2 c_j + 1.  Consecutive lanes then touch consecutive 16-byte chunks in
+  // LDS and in HBM, so the gate gradients go to dg straight from the registers of the cell backward (coalesced,
+  // non-temporal) and their write acknowledgements return while the rest of the cell phase computes -- issued around
+  // the GEMMs they stalled the weight-fragment ring, because stores and loads share the in-order vmcnt counter.
+  const int tc_ = tid % TPR;
+  struct Saved { u32x4 g[4]; unsigned ct[4], cp[4], dh[4]; };     // packed bf16 pairs: 28 VGPRs
+  auto ld_nt4 = [](const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p)); };
+  // carry: sv still holds the (consumed) state of step t + 1, whose "previous cell" c_t is this step's cell state:
+  // moved in registers instead of being read from HBM a second time
+  auto fetch = [&](Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t, bool carry) {
+    if (!prow_ok || t < 0) return;
+#ifdef C2_NO_FETCH
+    return;                               // diagnostic: timing without the saved-state loads (results are garbage)
+#endif
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));          // keep the per-chunk addresses out of the loop-invariant (spilled) set
+    const size_t e = ((size_t)t * N + row0 + prow) * H + cu * HC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tc + TPR * j;
+      sv.g[j] = ld_nt16(gs + e * 4 + 8 * c);
+      if (carry) sv.ct[j] = sv.cp[j];
+      else sv.ct[j] = ld_nt4(cs + e + 2 * c);
+      if (t > 0) sv.cp[j] = ld_nt4(cs + e - (size_t)N * H + 2 * c);
+      if (dh_ext) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
+    }
+  };
+  // The same for the chunks j0 <= j < j1 only, always with carry, and UNCONDITIONAL (time and row indices are clamped into
+  // the tensors; what a clamped request returns is never used): this is the form used inside the time loop, from the
+  // `post` hooks of the GEMM passes -- a load that only some paths issue makes hipcc's (path-insensitive) wait-count
+  // insertion drain the whole queue in front of the next fragment use.
+  const long prow_c = row0 + prow < N ? row0 + prow : N - 1;
+  auto fetch_part = [&](auto with_dh, Saved& sv, const T* gs, const T* cs, const T* dh_ext, int t, int j0, int j1) {
+#ifdef C2_NO_FETCH
+    return;
+#endif
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));
+    const int tcl = t > 0 ? t : 0, tpl = t > 1 ? t - 1 : 0;
+    const size_t e = ((size_t)tcl * N + prow_c) * H + cu * HC, ep = ((size_t)tpl * N + prow_c) * H + cu * HC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const int c = tc + TPR * j;
+      sv.g[j] = ld_nt16(gs + e * 4 + 8 * c);
+      sv.ct[j] = sv.cp[j];
+      sv.cp[j] = ld_nt4(cs + ep + 2 * c);
+      if constexpr (decltype(with_dh)::value) sv.dh[j] = ld_nt4(dh_ext + e + 2 * c);
+    }
+  };
+  auto lo16 = [](unsigned w) { return __uint_as_float(w << 16); };
+  auto hi16 = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
+  // cell backward -> gate gradients (bf16, local k = unit*4 + gate): LDS A operand + dg [t*N + row][4H] (own 768 columns)
+  // The phase has NO branch on the row being valid: rows past N compute on clamped (finite) saved state, their gate
+  // gradients are forced to zero for the LDS operand and their dg stores are dropped by the range check of the step's
+  // buffer descriptor (base = row 0 of time t, num_records = one time step).  A store that only some paths issue made
+  // hipcc wait for vmcnt(0) -- i.e. for the acknowledgement of the previous chunk's HBM store -- before every chunk.
+  auto cell_bwd = [&](const Saved& sv, const float* dh_lds, bool has_ext, float* dcl, int t, T* dg) {
+    int tc = tc_;
+    asm volatile("" : "+v"(tc));
+    const __amdgpu_buffer_rsrc_t dgr = make_rsrc(dg + (size_t)t * N * CB_K4, (unsigned)((size_t)N * CB_K4 * sizeof(T)));
+    const int rowoff = (int)(((row0 + prow) * CB_K4 + cu * C4_KC) * sizeof(T));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tc + TPR * j;
+      u32x4 out;
+      float2 dcv = *reinterpret_cast<const float2*>(dcl + prow * HC + 2 * c);
+      const float2 dhv = *reinterpret_cast<const float2*>(dh_lds + prow * HC + 2 * c);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned w0 = sv.g[j][2 * e], w1 = sv.g[j][2 * e + 1];   // (i, g), (f, o) of unit 2c + e
+        const float iv = lo16(w0), gv = hi16(w0), fv = lo16(w1), ov = hi16(w1);
+        const float ct = e ? hi16(sv.ct[j]) : lo16(sv.ct[j]);
+        const float cp = t > 0 ? (e ? hi16(sv.cp[j]) : lo16(sv.cp[j])) : 0.f;
+        float dh = e ? dhv.y : dhv.x;
+        if (has_ext) dh += e ? hi16(sv.dh[j]) : lo16(sv.dh[j]);
+        const float tch = tanh_f(ct);
+        const float dct = dh * ov * (1.f - tch * tch) + (e ? dcv.y : dcv.x);
+        const float dO = dh * tch * ov * (1.f - ov);
+        const float di = dct * gv * iv * (1.f - iv);
+        const float dgg = dct * iv * (1.f - gv * gv);
+        const float df = dct * cp * fv * (1.f - fv);
+        if (e) dcv.y = dct * fv; else dcv.x = dct * fv;
+        out[2 * e] = (uint32_t)f2bf(di) | ((uint32_t)f2bf(dgg) << 16);
+        out[2 * e + 1] = (uint32_t)f2bf(df) | ((uint32_t)f2bf(dO) << 16);
+      }
+      if (!prow_ok) { out = u32x4{0u, 0u, 0u, 0u}; dcv = float2{0.f, 0.f}; }
+      *reinterpret_cast<float2*>(dcl + prow * HC + 2 * c) = dcv;
+#ifndef C2_NO_DG
+      __builtin_amdgcn_raw_buffer_store_b128(out, dgr, rowoff + 16 * c, 0, 2);       // aux 2 = nt
+#endif
+      *reinterpret_cast<u32x4*>(Abuf + prow * RSA + 8 * c) = out;
+    }
+  };
+  auto pack4 = [](const f32x4 (&acc)[4], int half) {
+    u32x4 o;
+    o[0] = (uint32_t)f2bf(acc[2 * half][0]) | ((uint32_t)f2bf(acc[2 * half][1]) << 16);
+    o[1] = (uint32_t)f2bf(acc[2 * half][2]) | ((uint32_t)f2bf(acc[2 * half][3]) << 16);
+    o[2] = (uint32_t)f2bf(acc[2 * half + 1][0]) | ((uint32_t)f2bf(acc[2 * half + 1][1]) << 16);
+    o[3] = (uint32_t)f2bf(acc[2 * half + 1][2]) | ((uint32_t)f2bf(acc[2 * half + 1][3]) << 16);
+    return o;
+  };
+  auto add4 = [](f32x4 (&acc)[4], const u32x4 (&v)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const unsigned w0 = v[mt >> 1][2 * (mt & 1)], w1 = v[mt >> 1][2 * (mt & 1) + 1];
+      acc[mt][0] += __uint_as_float(w0 << 16);
+      acc[mt][1] += __uint_as_float(w0 & 0xffff0000u);
+      acc[mt][2] += __uint_as_float(w1 << 16);
+      acc[mt][3] += __uint_as_float(w1 & 0xffff0000u);
+    }
+  };
+  // this wave's own output tile (accumulators with all partials added) -> the fp32 LDS buffer of the outputs
+  auto scatter = [&](const f32x4 (&acc)[4], int layer) {
+    int n = n_, q = q_;
+    asm volatile("" : "+v"(n), "+v"(q));
+    int ld_own = HC;
+    float* own_dst;
+    bool overwrite = true;
+    if (layer == 1) {          // LSTM layer 2: waves 0-5 d h1 (accumulate onto the recurrent part), waves 6-11 d h2 rec
+      own_dst = (wave < 6 ? dh1buf : dhrec2) + (wave % 6) * 16;
+      overwrite = wave >= 6;
+    } else if (wave < 6) {     // LSTM layer 1: d h1 rec
+      own_dst = dh1buf + wave * 16;
+    } else {                   // LSTM layer 1, wave 6: the CU's 16 columns of d x
+      own_dst = dxbuf;
+      ld_own = 16;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = own_dst + (16 * mt + 4 * q + j) * ld_own + n;
+        *d = overwrite ? acc[mt][j] : *d + acc[mt][j];
+      }
+  };
+
+  // HEAD: the dY rows of a step (64 x 32 B) by two LDS-DMA instructions issued by every wave (same bytes, same place)
+  auto dy_dma = [&](int tau) {
+    if constexpr (HEAD) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      const int tcl = tau > 0 ? tau : 0;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.dyt) + (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16;
+      const unsigned lb = (unsigned)(unsigned long)(lds_void*)dys;
+      c4_lds_dma16(src, lb);
+      c4_lds_dma16(src + 1024, lb + 1024);
+    }
+  };
+
+  auto layer_gemm = [&](auto layer_c, const void* wpacked, int ep, Saved& nsv, const T* ngs, const T* ncs, const T* ndh, int nt) {
+    constexpr int layer = decltype(layer_c)::value;
+    constexpr bool l2 = layer == 1;
+    typedef std::integral_constant<bool, l2 && !HEAD> with_dh;
+    constexpr int RD = C4_DEPTH - 1;
+    constexpr C4Sched<(l2 && HEAD) ? 2 : 0, RD> sch{};
+    const bool active = l2 || wave < 7;                // layer 1 has 7 output tiles per owner: waves 7-11 only fetch their saved state
+    if (!active) {
+      fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, 4);
+    } else {
+      const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wpacked) + (size_t)(cu * CB_NW + wave) * C4_WFRAG;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int slabs = (layer * 2 + (ep & 1)) * C4_G * 3 * C4_SLAB;        // byte offset of (layer, parity); + (src * 3 + shipment) * C4_SLAB
+      const int my = (wave * 64 + ln) * 32;
+      gu32* lflags = flags + layer * (C4_G * 3 * CB_NW);                     // [src cu][shipment][wave]
+      int zoff = 0, lane16 = ln * 16;
+      asm volatile("" : "+v"(zoff));
+      // fragment bases of the four passes (owner cu + 1, cu + 2, cu + 3, cu): opaque per layer, or 48 addresses are hoisted and spilled
+      const unsigned char* wp0 = wbase + ((cu + 1) & 3) * 1024;
+      const unsigned char* wp1 = wbase + ((cu + 2) & 3) * 1024;
+      const unsigned char* wp2 = wbase + ((cu + 3) & 3) * 1024;
+      const unsigned char* wp3 = wbase + cu * 1024;
+      asm volatile("" : "+s"(wp0), "+s"(wp1), "+s"(wp2), "+s"(wp3));
+      auto frag_ptr = [&](int g) { return (g < 12 ? wp0 : (g < 24 ? wp1 : (g < 36 ? wp2 : wp3))) + (g % 12) * (C4_G * 1024); };
+      // receive side: cu + 3 (= cu - 1) shipped my tile in ITS pass 0, cu + 2 in its pass 1, cu + 1 in its pass 2
+      const gu32* pfa = lflags + (((cu + 3) & 3) * 3 + 0) * CB_NW + wave;
+      const gu32* pfb = lflags + (((cu + 2) & 3) * 3 + 1) * CB_NW + wave;
+      const gu32* pfc = lflags + (((cu + 1) & 3) * 3 + 2) * CB_NW + wave;
+      const int offa = slabs + (((cu + 3) & 3) * 3 + 0) * C4_SLAB + my, offb = slabs + (((cu + 2) & 3) * 3 + 1) * C4_SLAB + my,
+                offc = slabs + (((cu + 1) & 3) * 3 + 2) * C4_SLAB + my;
+      unsigned fla = 0, flb = 0;
+      u32x4 pa[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, pb[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+      auto poll = [&](unsigned& fl, const gu32* pf) {   // (no exit with a request pending)
+#ifdef C4_DIAG_NOPOLL
+        return;                                         // diagnostic: never wait for a partner (garbage results, timing only)
+#endif
+        unsigned spins = 0;
+        while (CF_POLL && fl < (unsigned)ep) {
+          if (++spins > SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          fl = __hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
+      bf16x8 b[C4_DEPTH];
+      f32x4 acc[4];
+#pragma unroll
+      for (int d = 0; d < RD; ++d) b[d] = c2_ring_load(frag_ptr(d), lane16);
+      // (static_for: the position is a template constant of each step -- a 48-iteration `#pragma unroll` loop of this size was
+      // only partially unrolled, leaving the waits as run-time switch ladders and the ring as indexed registers)
+      c4_static_for<48>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, k = g % 12, p = g / 12;
+        // ---- side
+        if constexpr (g == 20 || g == 32 || g == 44) {  // shipment (g - 20) / 12 acknowledged -> this wave's epoch for it
+          constexpr int q = (g - 20) / 12;
+          c4_wait_mem(sch.wait_raise(q));
+          if (lane == 0) __hip_atomic_store(lflags + (cu * 3 + q) * CB_NW + wave, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (g == 24) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(fla) : "v"(zoff), "s"(pfa) : "memory");
+        if constexpr (g == 36) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(flb) : "v"(zoff), "s"(pfb) : "memory");
+        if constexpr (g == 28) {
+          c4_wait_reg(sch.wait_flag(24), fla);
+          poll(fla, pfa);
+          pa[0] = load_sc1_b128(xr, offa);
+          pa[1] = load_sc1_b128(xr, offa + 16);
+        }
+        if constexpr (g == 40) {
+          c4_wait_reg(sch.wait_flag(36), flb);
+          poll(flb, pfb);
+          pb[0] = load_sc1_b128(xr, offb);
+          pb[1] = load_sc1_b128(xr, offb + 16);
+        }
+        // ---- request, wait, MFMAs
+        if constexpr (g + RD < 48) b[(g + RD) % C4_DEPTH] = c2_ring_load(frag_ptr(g + RD), lane16);
+        c2_wait(sch.wait_frag(g), b[g % C4_DEPTH]);
+        if constexpr (k == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (p == 3) add4(acc, pa);          // the own tile starts from cu - 1's partials
+        }
+        bf16x8 af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RSA + 32 * k);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mma16(af[mt], b[g % C4_DEPTH], acc[mt]);
+        // ---- tail: ship the finished partner tile
+        if constexpr (k == 11 && p < 3) {
+          if constexpr (p == 0 && l2) dy_dma(nt);
+          store_sc1_b128(xr, slabs + (cu * 3 + p) * C4_SLAB + my, pack4(acc, 0));
+          store_sc1_b128(xr, slabs + (cu * 3 + p) * C4_SLAB + my + 16, pack4(acc, 1));
+        }
+      });
+      add4(acc, pb);
+      // cu + 1 shipped these tiles in its pass 2 and raised the epoch two thirds into its own pass: normally there by now.  Its
+      // two loads go out FIRST, then the saved state of this layer's next step (younger: the wait for the partials leaves it in flight)
+#ifdef C4_DIAG_NOFINAL
+      fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, 4);      // diagnostic: the last partner's partials are not fetched (garbage results)
+#else
+      unsigned flc = __hip_atomic_load(pfc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      poll(flc, pfc);
+      u32x4 pc[2];
+      pc[0] = load_sc1_b128(xr, offc);
+      pc[1] = load_sc1_b128(xr, offc + 16);
+      fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, 4);
+      add4(acc, pc);
+#endif
+      scatter(acc, layer);
+    }
+    __syncthreads();                                   // the layer's outputs complete in LDS
+  };
+
+  // HEAD: + dY_tau . Wh restricted to the own units: waves 6-11 own the d h2 tiles
+  auto head_add = [&]() {
+    if constexpr (HEAD) {
+      if (wave >= 6) {
+        int nn = lane & 15, qq = lane >> 4;
+        asm volatile("" : "+v"(nn), "+v"(qq));
+        const int lt = wave - 6;
+        bf16x8 bfr = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qq < 2) bfr = load_frag<T>(whs + (16 * lt + nn) * 16 + 8 * qq);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          bf16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (qq < 2) af = load_frag<T>(dys + (16 * mt + nn) * 16 + 8 * qq);
+          const f32x4 hv = mma16(af, bfr, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dhrec2[(16 * mt + 4 * qq + j) * HC + 16 * lt + nn] += hv[j];
+        }
+      }
+    }
+  };
+  const T* dh2_src = HEAD ? nullptr : dh2;
+
+  Saved sv2, sv1;
+  fetch(sv2, g2, c2, dh2_src, a.Tn - 1, false);
+  fetch(sv1, g1, c1, nullptr, a.Tn - 1, false);
+  if constexpr (HEAD) {
+    dy_dma(a.Tn - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    head_add();
+    __syncthreads();
+  }
+
+#pragma unroll 1
+  for (int t = a.Tn - 1; t >= 0; --t) {
+    const int ep = a.Tn - t;
+    // ---------------- LSTM layer 2 (exchange layer index 1)
+    cell_bwd(sv2, dhrec2, !HEAD, dc2, t, dg2T);
+    __syncthreads();                                   // own dgates complete in LDS; everyone done reading dhrec2
+    layer_gemm(std::integral_constant<int, 1>{}, a.wb2, ep, sv2, g2, c2, dh2_src, t - 1);
+    if (t > 0) head_add();
+    // ---------------- LSTM layer 1 (exchange layer index 0)
+    cell_bwd(sv1, dh1buf, false, dc1, t, dg1T);
+    __syncthreads();
+    layer_gemm(std::integral_constant<int, 0>{}, a.wb1, ep, sv1, g1, c1, nullptr, t - 1);
+    int ti = tid;
+    asm volatile("" : "+v"(ti));
+    for (int i = ti; i < MC * 16; i += NT) {
+      const int r = i / 16, c = i % 16;
+      if (row0 + r < N) store1_nt<T>(dx + ((size_t)t * N + row0 + r) * KX + cu * 16 + c, dxbuf[i]);
+    }
+  }
+}
+
+// packed weights of the four-CU backward: element (cu, wave, kk, owner, lane l, j)
+//   local k = 32*kk + 8*(l>>4) + j = ul*4 + g'  (unit u = cu*96 + ul, g' in i,g,f,o -> torch block {0,2,1,3}[g'])
+//   column of (owner O, wave w, n = l&15):
+//   LSTM layer 2: w < 6 -> W_ih[row][96 O + 16 w + n] (input feature h1);  w >= 6 -> W_hh[row][96 O + 16 (w-6) + n]
+//   LSTM layer 1: w < 6 -> W_hh[row][96 O + 16 w + n];  w == 6 -> W_ih[row][16 O + n] (0 for 16 O + n >= I);  w > 6 -> 0
+__global__ void lstm_coop_pack_bwd4_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, bf16_t* __restrict__ out,
+                                           int I, int layer) {
+  const size_t total = (size_t)C4_G * CB_NW * C4_NKK * C4_G * 512;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e % 8), l = (int)((e / 8) % 64);
+    size_t f = e / 512;
+    const int owner = (int)(f % C4_G); f /= C4_G;
+    const int kk = (int)(f % C4_NKK); f /= C4_NKK;
+    const int wave = (int)(f % CB_NW);
+    const int cu = (int)(f / CB_NW);
+    const int k = 32 * kk + 8 * (l >> 4) + j, ul = k / 4, gp = k % 4;
+    const int tg = gp == 0 ? 0 : (gp == 1 ? 2 : (gp == 2 ? 1 : 3));
+    const int row = tg * CB_H + cu * C4_HC + ul;
+    const int n = l & 15;
+    float v = 0.f;
+    if (layer == 2) {
+      const int c = owner * C4_HC + 16 * (wave % 6) + n;
+      v = wave < 6 ? w_ih[(size_t)row * CB_H + c] : w_hh[(size_t)row * CB_H + c];
+    } else if (wave < 6) {
+      v = w_hh[(size_t)row * CB_H + owner * C4_HC + 16 * wave + n];
+    } else if (wave == 6) {
+      const int xc = owner * 16 + n;
+      v = xc < I ? w_ih[(size_t)row * I + xc] : 0.f;
+    }
+    out[e] = f2bf(v);
+  }
+}
+
 // packed weights of the K-split backward: element (cu, wave, kk, slot, lane l, j)
 //   local k = 32*kk + 8*(l>>4) + j = ul*4 + g'  (unit u = cu*192 + ul, g' in i,g,f,o -> torch block {0,2,1,3}[g'])
 //   column tile tau = wave + 12*slot, column c = 16*tau + (l&15)
@@ -1639,6 +2131,57 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
     hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<true>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
   else
     hipLaunchKernelGGL(lstm2_coop_bwd2_kernel<false>, dim3(round_up(clusters * CB_G, 8)), dim3(CB_NT), smem, s, a);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// four-CU K-split backward (lstm2_coop_bwd4_kernel): same tensor contract as nppc_lstm2_bwd_coop2 / _head (dh2 == null
+// selects the fused head: dyt + whT); workspace sizes from nppc_lstm2_coop_bwd4_sizes
+int nppc_lstm2_coop_bwd4_sizes(long N, long* packed_elems, long* xch_bytes, long* flag_words) {
+  if (N <= 0 || !packed_elems || !xch_bytes || !flag_words) return NPPC_EBADARG;
+  const long clusters = (N + C4_MC - 1) / C4_MC;
+  *packed_elems = (long)C4_G * CB_NW * C4_NKK * C4_G * 512;
+  *xch_bytes = clusters * C4_XCH;
+  *flag_words = clusters * C4_FPC + 4;
+  return NPPC_OK;
+}
+
+int nppc_lstm2_coop_bwd4_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                              void* wb2, void* stream) {
+  if (!w_ih0 || !w_hh0 || !w_ih1 || !w_hh1 || !wb1 || !wb2 || I > CB_KX) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lstm_coop_pack_bwd4_kernel, dim3(512), dim3(256), 0, s, w_ih0, w_hh0, (bf16_t*)wb1, I, 1);
+  hipLaunchKernelGGL(lstm_coop_pack_bwd4_kernel, dim3(512), dim3(256), 0, s, w_ih1, w_hh1, (bf16_t*)wb2, CB_H, 2);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+int nppc_lstm2_bwd_coop4(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* dyt,
+                         const void* whT, const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch,
+                         long xch_bytes, unsigned* flags, long N, int Tn, int n_cu, void* stream) {
+  if (!g1 || !g2 || !c1 || !c2 || (!dh2 && !(dyt && whT)) || !wb1 || !wb2 || !dx || !dg1 || !dg2 || !xch || !flags || N <= 0 ||
+      Tn <= 0)
+    return NPPC_EBADARG;
+  const int clusters = (int)((N + C4_MC - 1) / C4_MC);
+  if (clusters * C4_G > n_cu) return NPPC_EUNSUPPORTED;      // every workgroup of a cluster must be resident
+  if (xch_bytes < (long)clusters * C4_XCH) return NPPC_EBADARG;
+  CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dh2 ? nullptr : dyt, dh2 ? nullptr : whT};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr size_t smem = (size_t)C4_MC * (C4_KC + 8) * 2 + (size_t)4 * C4_MC * C4_HC * 4 + (size_t)C4_MC * 16 * 4 +
+                          (size_t)(C4_HC + C4_MC) * 16 * 2;
+  static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
+  const bool head = !dh2;
+  const void* k = head ? reinterpret_cast<const void*>(lstm2_coop_bwd4_kernel<true>)
+                       : reinterpret_cast<const void*>(lstm2_coop_bwd4_kernel<false>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return NPPC_ELAUNCH;
+  static int per_cu[2] = {-1, -1};
+  const int fits = coop_fits(k, CB_NT, smem, clusters * C4_G, per_cu[head ? 1 : 0]);
+  if (fits != NPPC_OK) return fits;
+  if (hipMemsetAsync(flags, 0, (size_t)clusters * C4_FPC * sizeof(unsigned), s) != hipSuccess) return NPPC_ELAUNCH;
+  if (head)
+    hipLaunchKernelGGL(lstm2_coop_bwd4_kernel<true>, dim3(round_up(clusters * C4_G, 8)), dim3(CB_NT), smem, s, a);
+  else
+    hipLaunchKernelGGL(lstm2_coop_bwd4_kernel<false>, dim3(round_up(clusters * C4_G, 8)), dim3(CB_NT), smem, s, a);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

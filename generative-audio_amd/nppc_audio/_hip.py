@@ -103,6 +103,9 @@ SIGS = {
     "nppc_lstm2_coop_bwd2_pack": [P, P, P, P, I, P, P, P],
     "nppc_lstm2_bwd_coop2": [P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
     "nppc_lstm2_bwd_coop2_head": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
+    "nppc_lstm2_coop_bwd4_sizes": [L, PL, PL, PL],
+    "nppc_lstm2_coop_bwd4_pack": [P, P, P, P, I, P, P, P],
+    "nppc_lstm2_bwd_coop4": [P, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, P],
     "nppc_head_dy_gather": [P, P, L, I, I, I, I, P],
     "nppc_sb_head_bwd_w": [I, P, P, P, P, L, I, I, I, I, I, P],
     "nppc_lstm2_bwd_packed_elems": [I, I, PL, PL],

@@ -159,6 +159,9 @@ def workspace(key, shape, dtype, device, zero=False):
 
 
 COOP_BWD_KSPLIT = True    # cooperative backward variant: True = K-split (bf16 partial-sum exchange), False = output-split
+# K-split backward on four-CU clusters of 64 sequences instead of CU pairs of 32 (half the weight-fragment bytes per CU and step):
+# "1" whenever ceil(N / 64) * 4 CUs are free, "0" never
+BWD_G4 = os.environ.get("NPPC_LSTM_BWD_G4", "0")
 WGRAD_SPLITS = int(os.environ.get("NPPC_WGRAD_SPLITS", "64"))    # K-slices of the weight-gradient GEMMs (engine._lstm_wgrad)
 ROW_PAD = 64 * WGRAD_SPLITS   # row granularity of their operands: 64-row stages x K-slices; buffers carry this much slack
 
@@ -307,6 +310,10 @@ class PackedLSTMBwd:
             H.call("nppc_lstm2_coop_bwd2_packed_elems", ctypes.byref(nc))
             self.kwb1 = torch.empty(nc.value, dtype=dt, device=device)     # K-split variant
             self.kwb2 = torch.empty(nc.value, dtype=dt, device=device)
+            n4, nx, nf = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+            H.call("nppc_lstm2_coop_bwd4_sizes", 64, ctypes.byref(n4), ctypes.byref(nx), ctypes.byref(nf))
+            self.k4wb1 = torch.empty(n4.value, dtype=dt, device=device)    # K-split on four-CU clusters
+            self.k4wb2 = torch.empty(n4.value, dtype=dt, device=device)
 
     def pack(self, w_ih0, w_hh0, w_ih1, w_hh1):
         ws = [t.detach().contiguous() for t in (w_ih0, w_hh0, w_ih1, w_hh1)]
@@ -314,6 +321,8 @@ class PackedLSTMBwd:
         if self.coop:
             if COOP_BWD_KSPLIT:
                 H.call("nppc_lstm2_coop_bwd2_pack", *ws, self.I, self.kwb1, self.kwb2, H.stream())
+                if BWD_G4 != "0":
+                    H.call("nppc_lstm2_coop_bwd4_pack", *ws, self.I, self.k4wb1, self.k4wb2, H.stream())
             else:
                 H.call("nppc_lstm2_coop_bwd_pack", *ws, self.I, self.cwb1, self.cwb2, H.stream())
         return self
@@ -337,6 +346,16 @@ def lstm2_backward(saved, dh2, packed_bwd, kx, coop=None, head=None):
     dg1 = workspace(tag + ("dg1",), (Rp, 4 * Hd), dt, dev, zero=True)
     dg2 = workspace(tag + ("dg2",), (Rp, 4 * Hd), dt, dev, zero=True)
     use_coop = (COOP if coop is None else coop) and packed_bwd.coop and ((N + 31) // 32) * 2 <= _n_cu()
+    if use_coop and COOP_BWD_KSPLIT and BWD_G4 != "0" and ((N + 63) // 64) * 4 <= _n_cu():
+        npk, nx, nf = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+        H.call("nppc_lstm2_coop_bwd4_sizes", N, ctypes.byref(npk), ctypes.byref(nx), ctypes.byref(nf))
+        xch = workspace(tag + ("coop_xch4",), (nx.value,), torch.uint8, dev)
+        flags = workspace(tag + ("g4", "coop_flags"), (nf.value,), torch.int32, dev, zero=True)
+        dyt, whT = head if head is not None else (None, None)
+        _timed(("lstm2_bwd_coop_ksplit_g4", 1, N, Tn, 4), lambda: H.call(
+            "nppc_lstm2_bwd_coop4", saved["g1"], saved["g2"], saved["c1"], saved["c2"], dh2 if head is None else None, dyt, whT,
+            packed_bwd.k4wb1, packed_bwd.k4wb2, dx, dg1, dg2, xch, nx.value, flags, N, Tn, _n_cu(), H.stream()))
+        return dx, dg1, dg2
     if use_coop and COOP_BWD_KSPLIT:
         ncl = (N + 31) // 32
         xch = workspace(tag + ("coop_xch",), (ncl * 2 * 2 * 2 * 32 * 384,), dt, dev)

@@ -249,6 +249,17 @@ int nppc_lstm2_bwd_coop2(const void* g1, const void* g2, const void* c1, const v
 int nppc_lstm2_bwd_coop2_head(const void* g1, const void* g2, const void* c1, const void* c2, const void* dyt, const void* whT,
                               const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch, long xch_bytes,
                               unsigned* flags, long N, int Tn, int n_cu, void* stream);
+/* The same K-split backward on FOUR-CU clusters of 64 sequences (each CU owns 96 hidden units and streams a quarter of the weight
+ * fragments per step; three bf16 partial-sum shipments per layer and step, accumulator to accumulator, per-wave epochs).  Same
+ * tensor contract as nppc_lstm2_bwd_coop2 / _head: dh2 != null, or dh2 == null with the fused head's dyt + whT.  Needs
+ * ceil(N / 64) * 4 <= n_cu.  nppc_lstm2_coop_bwd4_sizes: elements of each packed weight buffer (nppc_lstm2_coop_bwd4_pack),
+ * bytes of xch and u32 words of flags (epochs + the 4 sticky time-out words) for N sequences. */
+int nppc_lstm2_coop_bwd4_sizes(long N, long* packed_elems, long* xch_bytes, long* flag_words);
+int nppc_lstm2_coop_bwd4_pack(const float* w_ih0, const float* w_hh0, const float* w_ih1, const float* w_hh1, int I, void* wb1,
+                              void* wb2, void* stream);
+int nppc_lstm2_bwd_coop4(const void* g1, const void* g2, const void* c1, const void* c2, const void* dh2, const void* dyt,
+                         const void* whT, const void* wb1, const void* wb2, void* dx, void* dg1, void* dg2, void* xch,
+                         long xch_bytes, unsigned* flags, long N, int Tn, int n_cu, void* stream);
 int nppc_head_dy_gather(const float* dout, void* dyt, long Nseq, int Tn, int la, int O, int Fo, void* stream);
 int nppc_sb_head_bwd_w(int prec, const float* dout, const void* h2, float* dWh, float* dbh, long Nseq, int Tn, int la, int Hd,
                        int O, int Fo, void* stream);

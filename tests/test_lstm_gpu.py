@@ -205,6 +205,53 @@ def test_cooperative_backward_matches_single_workgroup_kernel(N, Tn):
         assert d < 2e-2, (name, d)
 
 
+@pytest.mark.parametrize("N,Tn,head", [(192, 7, False), (160, 5, True), (77, 6, True), (640, 4, False)])
+def test_four_cu_cluster_backward_matches_cu_pair_backward(N, Tn, head, monkeypatch):
+    """The K-split backward on four-CU clusters of 64 sequences (lstm2_coop_bwd4_kernel: three partial-sum shipments per layer and
+    step in one continuous fragment stream; opt-in, NPPC_LSTM_BWD_G4=1) against the CU-pair kernel and the single-workgroup
+    kernel: ragged last clusters (160 = 2.5 x 64, 77), with d h2 given and with the fused head backward; no time-outs."""
+    from nppc_audio import ops_lstm
+    from nppc_audio.ops_lstm import PackedLSTM, PackedLSTMBwd, lstm2_forward, lstm2_backward
+    I, Hd, O = 34, 384, 10
+    P = _weights(I, Hd, 5)
+    pre = "sb_model.sequence_model."
+    dev = torch.device("cuda")
+    names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l1", "weight_hh_l1", "bias_ih_l1", "bias_hh_l1")
+    wnames = ("weight_ih_l0", "weight_hh_l0", "weight_ih_l1", "weight_hh_l1")
+    pk = PackedLSTM(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in names])
+    monkeypatch.setattr(ops_lstm, "BWD_G4", "1")
+    pb = PackedLSTMBwd(I, Hd, 0, dev).pack(*[P[pre + n].to(dev) for n in wnames])      # packs the four-CU layout as well
+    g = torch.Generator().manual_seed(N + Tn)
+    xt = torch.zeros(Tn, N, pk.kx, dtype=torch.bfloat16, device=dev)
+    xt[:, :, :I] = torch.randn(Tn, N, I, generator=g).to(dev)
+    saved = lstm2_forward(xt, pk, True, 1)
+    if head:
+        dyt = torch.zeros(Tn, N, 16, dtype=torch.bfloat16, device=dev)
+        dyt[:, :, :O] = (torch.randn(Tn, N, O, generator=g) * 0.1).to(dev)
+        whT = torch.zeros(Hd, 32, dtype=torch.bfloat16, device=dev)
+        whT[:, :O] = (torch.randn(Hd, O, generator=g) * 0.1).to(dev)
+        args = dict(dh2=None, head=(dyt, whT))
+    else:
+        args = dict(dh2=torch.randn(Tn, N, Hd, generator=g).to(dev).to(torch.bfloat16), head=None)
+    ops_lstm.clear_coop_timeouts()
+    four = [t.clone() for t in lstm2_backward(saved, args["dh2"], pb, pk.kx, coop=True, head=args["head"])]
+    monkeypatch.setattr(ops_lstm, "BWD_G4", "0")
+    pair = [t.clone() for t in lstm2_backward(saved, args["dh2"], pb, pk.kx, coop=True, head=args["head"])]
+    torch.cuda.synchronize()
+    assert ops_lstm.coop_timeouts() == 0
+    R_ = Tn * N
+    for name, x, y in zip(("dx", "dg1", "dg2"), four, pair):
+        x, y = (x[:R_].float(), y[:R_].float()) if x.dim() == 2 else (x.float(), y.float())
+        assert bool(torch.isfinite(x).all()), name
+        d = (x - y).abs().max().item() / (y.abs().max().item() + 1e-30)
+        assert d < 2e-2, (name, d)            # both bf16 kernels: the partial sums are rounded to bf16 at different places
+    if not head:
+        single = [t.clone() for t in lstm2_backward(saved, args["dh2"], pb, pk.kx, coop=False)]
+        for name, x, y in zip(("dx", "dg1", "dg2"), four, single):
+            x, y = (x[:R_].float(), y[:R_].float()) if x.dim() == 2 else (x.float(), y.float())
+            assert (x - y).abs().max().item() / (y.abs().max().item() + 1e-30) < 2e-2, name
+
+
 @pytest.mark.parametrize("N,Tn,force,O,Fo,la", [(96, 9, (2, 2), 2, 48, 2), (200, 7, (2, 5), 2, 100, 0), (161, 5, (2, 5), 4, 161, 1)])
 def test_fused_head_equals_separate_head_kernel(N, Tn, force, O, Fo, la):
     """inference: Linear(H -> O) fused into the CU-pair kernel (per-CU partial sums + nppc_sb_head_finalize) against the

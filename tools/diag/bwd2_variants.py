@@ -3,7 +3,8 @@
   python tools/diag/bwd2_variants.py              (GPU box: one process per variant, C2 shape N=4096, T'=253, fused head)"""
 import glob, os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-VARIANTS = {"base": [], "r02": []}
+VARIANTS = {"base": [], "g4_d4": ["-DC4_DEPTH=4"], "g4_d6": ["-DC4_DEPTH=6"], "g4_d8": ["-DC4_DEPTH=8"], "g4_d10": ["-DC4_DEPTH=10"],
+            "g4_d8_nodg_nofetch": ["-DC4_DEPTH=8", "-DC2_NO_DG", "-DC2_NO_FETCH"]}       # "g4*": the four-CU kernel (NPPC_LSTM_BWD_G4=1)
 R02_REV = "HEAD"        # "r02" variant = lstm_coop.hip of that commit for A/B on one box
 so = lambda n: os.path.join(root, "tools", "diag", f"libv_{n}.so")
 if "--build" in sys.argv:
@@ -23,6 +24,8 @@ if "--build" in sys.argv:
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     name = sys.argv[2]
+    if name.startswith("g4"):
+        os.environ["NPPC_LSTM_BWD_G4"] = "1"
     sys.path.insert(0, os.path.join(root, "generative-audio_amd"))
     import torch
     from nppc_audio import _hip as H
