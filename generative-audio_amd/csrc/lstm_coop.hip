@@ -200,7 +200,9 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   constexpr int OX0 = 0, OX1 = KX, OH1 = 2 * KX, OH2 = 2 * KX + H;
   constexpr int NKX = KX / 32, NKH = H / 32;
   constexpr int nk1 = NKX + NKH, nk2 = 2 * NKH;
-  constexpr int DEPTH = (MT <= 2 || G >= 4) ? 4 : 2;              // weight-fragment ring depth the register budget allows
+  // weight-fragment ring depth the register budget allows (80-row variant: depth 3 spills 3 registers and takes 9.5 instead of
+  // 8.8 ms, depth 4 spills 24: 9.9 ms)
+  constexpr int DEPTH = (MT <= 2 || G >= 4) ? 4 : 2;
   constexpr int SLICE = MC * HC;                                  // elements of one CU's h slice
   constexpr int SLICE_CH = SLICE * (int)sizeof(T) / 16;           // 16-byte chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -865,17 +867,11 @@ constexpr int C2_NKK = CB_KC / 32;                          // 24 k-steps over t
 constexpr int C2_SLOTS = 4;                                 // column tiles per wave (layer 2: 4, layer 1: 2 or 3)
 constexpr int C2_FPC = 2 * CB_G * CB_NW;                     // epoch words per cluster: [layer 2][cu 2][wave 12] (every wave hands off its own tiles)
 constexpr int C2_XW = 2 * CB_HC;                            // 384 partial columns exchanged per row (layer 1 uses 224)
-#ifndef C2_FSPLIT
-#define C2_FSPLIT 0                                         // saved-state chunks (of 4) requested behind pass 0; the rest behind pass 1
-#endif
 #ifndef C2_DEPTH
 #define C2_DEPTH 4                                          // fragment ring: C2_DEPTH - 1 k-steps requested ahead
 #endif
 #ifndef C2_KBAR
 #define C2_KBAR 8                                           // k-steps between the in-pass barriers that keep the waves in step (0: none)
-#endif
-#ifndef C2_XROUND
-#define C2_XROUND 4                                         // ring round of the own-tile pass in which the partner's partials are requested
 #endif
 
 // B fragment (cu, wave, kk, slot): [cu][wave][kk][slot][lane][8]
@@ -890,12 +886,12 @@ __device__ __forceinline__ int c2_frag_boff(int cu, int wave, int kk, int slot) 
 // The compiler's wait-count insertion cannot follow a register ring through a loop: for the rolled loop of round 2 it
 // emitted vmcnt(7,6),(5,4),(3,2),(1,0) within every four k-steps, i.e. the ring was DRAINED by the fourth k-step of each
 // round (prefetch distance 3 -> 0), and any other request placed inside the pass (the partner's partials, the next
-// phase's saved state) was waited for right there.  Here the pass is fully unrolled, the fragment requests go out
-// through inline asm (invisible to the pass), and every wait is `s_waitcnt vmcnt(M)` with M = the number of vector-memory
-// operations issued AFTER the fragment pair that is about to be used -- ring requests plus whatever the hooks below
-// issue at their fixed places (the hooks declare their operation counts).  vmcnt retires in order, so M younger
-// operations may still be in flight.  M must never exceed the true count; operations the model does not know (the rare
-// poll loop) only make a wait stricter.
+// phase's saved state) was waited for right there.  Here a layer's GEMM is one fully unrolled fragment stream (every
+// position a template constant), the fragment requests go out through inline asm (invisible to the pass), and every wait
+// is `s_waitcnt vmcnt(M)` with M = the number of vector-memory operations issued AFTER the fragment pair that is about to
+// be used -- ring requests plus whatever else is issued at fixed positions of the stream; the counts come from a
+// compile-time table (C2Sched / C4Sched).  vmcnt retires in order, so M younger operations may still be in flight.  M must
+// never exceed the true count; operations the table does not know (the rare poll loop) only make a wait stricter.
 __device__ __forceinline__ bf16x8 c2_ring_load(const unsigned char* frag /* wave-uniform: start of the 1 KB fragment */, int lane16) {
   bf16x8 v;
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lane16), "s"(frag) : "memory");
@@ -923,63 +919,6 @@ __device__ __forceinline__ void c2_wait(int m, bf16x8& x) {
 #undef C2_W
 }
 
-// One pass over the own K (24 k-steps) for NS (1 or 2) of this wave's column tiles (slot ids s0, s1).  Program order:
-//   requests for k-steps 0 .. D-1;  pre();  for k = 0..23: { k % 4 == 0: side(k / 4);  request k + D;  k == 23 - D: post();
-//   wait;  MFMAs of k-step k }      (D = C2_DEPTH - 1).
-// side(i) issues SOPS(i) vector-memory operations, post() issues POPS (both compile-time), pre() issues none that are
-// still outstanding when it returns.
-template <int NS, int XR /* partner-partials round of the own-tile pass, < 0: none */, int POPS, typename Pre, typename Side, typename Post>
-__device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane, const unsigned char* wbase /* (cu, wave) */,
-                                        int lane, int RS, int s0, int s1, Pre&& pre, Side&& side, Post&& post) {
-#ifdef C2_DIAG_HALFK
-  constexpr int DEPTH = C2_DEPTH, D = DEPTH - 1, NK = C2_NKK / 2;  // diagnostic: half the k-steps (garbage results; what half the fragment stream would buy)
-#else
-  constexpr int DEPTH = C2_DEPTH, D = DEPTH - 1, NK = C2_NKK;      // D = prefetch distance in k-steps
-#endif
-  static_assert(DEPTH >= 2 && D <= 8 && (XR < 0 || 4 * XR + D < NK), "ring depth / partner round out of the wait model's range");
-  bf16x8 b[DEPTH][2];
-  int lane16 = lane * 16;
-  asm volatile("" : "+v"(lane16));
-  auto sops = [](int i) { return XR < 0 ? 0 : (i == XR - 1 ? 1 : 0) + (i == XR ? NS : 0); };
-  const unsigned char* w0 = wbase + s0 * 1024;
-  const unsigned char* w1 = wbase + s1 * 1024;
-  asm volatile("" : "+s"(w0), "+s"(w1));        // opaque per pass: as loop invariants of the time loop the 2 x 24 fragment addresses were spilled
-  auto request = [&](bf16x8(&bb)[2], int kk) {
-    bb[0] = c2_ring_load(w0 + kk * (C2_SLOTS * 1024), lane16);
-    if (NS == 2) bb[1] = c2_ring_load(w1 + kk * (C2_SLOTS * 1024), lane16);
-  };
-#pragma unroll
-  for (int d = 0; d < D; ++d) request(b[d], d);
-  pre();
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    if (k % 4 == 0) side(k / 4);
-    if (k + D < NK) request(b[(k + D) % DEPTH], k + D);
-    if (k + D == NK - 1) post();
-    // keep the twelve waves of the workgroup in step (requests stay in flight across the barrier): left alone, the oldest
-    // wave wins every arbitration and finishes a pass in 6.5k cycles, the youngest needs 14.5k, and the tail of the pass
-    // runs on the few bytes the last waves keep in flight
-    if (C2_KBAR > 0 && k > 0 && k % C2_KBAR == 0) asm volatile("s_barrier" ::: "memory");
-    // younger than the pair of k-step k: the ring requests of k+1 .. min(k+D, 23); side(i) for every round boundary
-    // 4i in (issue position of pair k, k]; post() once it has run (k >= 23 - D)
-    int m = NS * ((k + D < NK ? k + D : NK - 1) - k);
-    const int lo = k >= D ? k - D + 1 : 0;                  // pair k was requested at loop position k - D, behind that position's side()
-#pragma unroll
-    for (int p = lo; p <= k; ++p)
-      if (p % 4 == 0) m += sops(p / 4);
-    if (k >= NK - 1 - D) m += POPS;
-    if constexpr (NS == 2) c2_wait(m, b[k % DEPTH][0], b[k % DEPTH][1]);
-    else c2_wait(m, b[k % DEPTH][0]);
-    bf16x8 af[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RS + 32 * k);
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[s][mt] = mma16(af[mt], b[k % DEPTH][s], acc[s][mt]);
-  }
-}
-
 // diagnostic phase timers (tools/diag/stamp_bwd2.py builds with -DC2_STAMP): thread 0 of workgroup 0 accumulates
 // s_memtime deltas per phase and leaves them behind the flag words
 #ifdef C2_STAMP
@@ -993,6 +932,70 @@ __device__ __forceinline__ void c2_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
 #define C2T(i)
 #endif
 
+
+template <int... I, typename F>
+__device__ __forceinline__ void c4_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void c4_static_for(F&& f) { c4_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// s_waitcnt vmcnt(m) for a compile-time m
+__device__ __forceinline__ void c4_wait_mem(int m) {
+#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (m) {
+    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12) C4_W(13) C4_W(14)
+    C4_W(15) C4_W(16) C4_W(17) C4_W(18) C4_W(19) C4_W(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef C4_W
+}
+__device__ __forceinline__ void c4_wait_reg(int m, unsigned& x) {
+#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x)); break;
+  switch (m) {
+    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); break;
+  }
+#undef C4_W
+}
+// 16 bytes per lane global -> LDS (lds_base + 16 * lane), through inline asm: invisible to the compiler's wait insertion, which
+// would otherwise drain the fragment ring in front of the next LDS read; completion is covered by a later counted wait
+__device__ __forceinline__ void c4_lds_dma16(const void* src_lane, unsigned lds_base /* wave-uniform */) {
+  unsigned keep;
+  const unsigned lb = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(lb) : "memory");
+}
+
+// Compile-time operation schedule of ONE fragment stream over both passes of a layer of the CU-pair kernel (48 k-steps: 24 on
+// the partner's tiles, 24 on the own ones; the ring never restarts between them and nothing is drained).  Per position g:
+//   side(g)   g = 32: raise the epoch of the shipment (1 store, behind a counted wait for its stores);  g = 36: request the
+//             partner's epoch (1 load);  g = 40: request its partials (NS1 loads)
+//   request of the NS0 / NS1 fragments of k-step g + D;  g = 47 - D: post (P1 saved-state loads)
+//   wait + MFMAs of k-step g
+//   tail(g)   g = 23: ship the partner's tiles (NS0 stores; layer 2 with the fused head: + 1 dY DMA in front of them)
+template <int NS0, int NS1, int DY, int P1, int D>
+struct C2Sched {
+  int before[49];    // vector-memory operations issued before side(pos)
+  int req_last[48];  // sequence number of the LAST fragment request of k-step g
+  static constexpr int ns(int g) { return g < 24 ? NS0 : NS1; }
+  static constexpr int side(int pos) { return (pos == 32 || pos == 36) ? 1 : (pos == 40 ? NS1 : 0); }
+  static constexpr int post(int pos) { return pos == 47 - D ? P1 : 0; }
+  static constexpr int tail(int pos) { return pos == 23 ? NS0 + DY : 0; }
+  constexpr C2Sched() : before{}, req_last{} {
+    int c = 0;
+    for (int g = 0; g < D; ++g) { c += ns(g); req_last[g] = c - 1; }
+    for (int pos = 0; pos < 48; ++pos) {
+      before[pos] = c;
+      c += side(pos);
+      if (pos + D < 48) { c += ns(pos + D); req_last[pos + D] = c - 1; }
+      c += post(pos);
+      c += tail(pos);
+    }
+    before[48] = c;
+  }
+  constexpr int wait_frag(int g) const { return before[g] + side(g) + (g + D < 48 ? ns(g + D) : 0) + post(g) - req_last[g] - 1; }
+  constexpr int wait_raise() const { return before[32] - before[24]; }         // since the shipment's last store
+  constexpr int wait_flag() const { return before[40] - before[36] - 1; }       // since the epoch request
+};
 
 template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
@@ -1213,30 +1216,32 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
   // issued by EVERY wave (same source, same destination, same bytes: 11 redundant L2 hits per step) and for tau = -1 too
   // (clamped): an instruction that only one wave / some steps issue is one more conditional memory operation for the
   // wait-count insertion to be pessimistic about.
-  const __amdgpu_buffer_rsrc_t dyr = make_rsrc(a.dyt, HEAD ? (unsigned)((size_t)a.Tn * N * 16 * sizeof(T)) : 0u);
   auto dy_dma = [&](int tau) {
     if constexpr (HEAD) {
       typedef __attribute__((address_space(3))) void lds_void;
       const int tcl = tau > 0 ? tau : 0;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void*)dys, 16, lane * 16,
-                                               (int)((((size_t)tcl * N + row0) * 16) * sizeof(T)), 0, 0);
+      c4_lds_dma16(reinterpret_cast<const unsigned char*>(a.dyt) + (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16,
+                   (unsigned)(unsigned long)(lds_void*)dys);
     }
   };
-  // `nsv` ... : the saved state of THIS layer's next (earlier) step, requested behind the last fragment request of each
-  // pass (its registers are free: this step's cell phase of the layer is over): C2_FSPLIT chunks behind pass 0, where the
-  // wave waits for its partial stores anyway, the rest behind pass 1, with the scatter, the barrier and the other layer's
-  // whole cell phase (ALU + LDS only) to arrive before the next GEMM's fragment ring queues up behind it.  (Round 2
-  // requested a phase's state right in front of the previous cell phase: 61 KB per CU take longer than that phase, and
-  // the first fragments of the following GEMM waited out the difference.)
+  // The two passes of a layer -- the partner's column tiles, shipped at once, then the own ones, to which the partner's
+  // partials are added in registers -- run as ONE fragment stream of 48 k-steps (C2Sched): the ring is not restarted and
+  // nothing is drained between them.  (The first round-3 version ended pass 0 with its stores, restarted the ring and
+  // waited for vmcnt(0) in front of the flag: 1.6-2.8k cycles per layer.)  The flag of a wave's shipment goes up eight
+  // k-steps into the own tiles, behind a counted wait that covers exactly the shipment's stores; the partner's partials
+  // are requested sixteen k-steps in; `nsv` ..., the saved state of THIS layer's next (earlier) step, behind the last
+  // fragment request (its registers are free: this step's cell phase of the layer is over), so that it has the scatter,
+  // the barrier and the other layer's whole cell phase to arrive before the next stream queues up behind it.
   auto layer_gemm = [&](auto layer_c, const void* wpacked, int ep, Saved& nsv, const T* ngs, const T* ncs, const T* ndh, int nt) {
     constexpr int layer = decltype(layer_c)::value;
     constexpr bool l2 = layer == 1;
     typedef std::integral_constant<bool, l2 && !HEAD> with_dh;             // only layer 2 without the fused head reads d h2
 #ifdef C2_NO_FETCH
-    constexpr int P0 = 0, P1 = 0;
+    constexpr int P1 = 0;
 #else
-    constexpr int P0 = C2_FSPLIT * (2 + (with_dh::value ? 1 : 0)), P1 = (4 - C2_FSPLIT) * (2 + (with_dh::value ? 1 : 0));
+    constexpr int P1 = 4 * (2 + (with_dh::value ? 1 : 0));
 #endif
+    constexpr int RD = C2_DEPTH - 1;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wpacked) + (size_t)(cu * CB_NW + wave) * (C2_NKK * C2_SLOTS * 1024);
     const bool xw = !l2 && wave < 4;                   // this wave also has a d x tile (slot 2)
     const int xo = wave >> 1;                          // ... owned by CU xo
@@ -1244,85 +1249,90 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     asm volatile("" : "+v"(ln));
     const int slab = ((layer * 2 + (ep & 1)) * 2) * XSL * 2;                      // byte offset of (layer, parity); + cu * XSL * 2
     const int my = (wave * 2 * 64 + ln) * 16;                                     // this lane's 16 bytes of tile 0; tile 1: + 1024
-    f32x4 acc[2][2];
-    {   // ---- pass 0: the partner's tiles
-      const int s0 = pcu, s1 = l2 ? pcu + 2 : 2;
-      const bool two = l2 || (xw && xo == pcu);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      auto none = []() {};
-      auto side = [](int) {};
-      auto post = [&]() { fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, C2_FSPLIT); };
-      if (two) c2_gemm<2, -1, P0>(acc, a_lane, wbase, lane, RSA, s0, s1, none, side, post);
-      else c2_gemm<1, -1, P0>(acc, a_lane, wbase, lane, RSA, s0, s1, none, side, post);
-      if (l2) { C2T(3) }
-      // HEAD: the dY rows of the next (earlier) step -- here, where the wave is about to wait for its partial stores anyway
-      // (in front of the cell phase their DMA sat in the queue that the phase's first use of the saved state waits on)
-      if (l2) dy_dma(nt);
-      store_sc1_b128(xr, slab + cu * XSL * 2 + my, pack_acc(acc[0]));
-      if (two) store_sc1_b128(xr, slab + cu * XSL * 2 + my + 1024, pack_acc(acc[1]));
-      if (l2) { C2T(4) }
-    }
-    {   // ---- pass 1: the own tiles
-      const int s0 = cu, s1 = l2 ? cu + 2 : 2;
-      const bool two = l2 || (xw && xo == cu);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // behind the first fragment requests: THIS wave's partial stores acknowledged -> its epoch flag.  A wave hands its
-      // tiles to the same wave of the partner, so the hand-off needs no workgroup barrier (Guideline 16 R1 per wave: the
-      // storing wave's vmcnt(0), then its flag): the waves of a workgroup drift apart by more than a third of a pass, and
-      // with a barrier here the early ones idled while the L2 pipe ran on the requests of the late ones.
-      auto pre = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(flags + (layer * CB_G + cu) * CB_NW + wave, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (l2) { C2T(5) }
-      };
-      // the partner's partials of these tiles: every wave looks at the partner's epoch itself (requested in ring round
-      // C2_XROUND - 1, examined in round C2_XROUND: by then it has normally arrived, the bounded poll is the exception) and
-      // then requests its 16 bytes per lane and tile; they arrive during the remaining rounds
+    gu32* myflag = flags + (layer * CB_G + cu) * CB_NW + wave;
+    const gu32* pflag = flags + (layer * CB_G + pcu) * CB_NW + wave;
+    int zoff = 0, lane16 = ln * 16;
+    asm volatile("" : "+v"(zoff));
+    auto stream = [&](auto ns0c, auto ns1c) __attribute__((always_inline)) {
+      constexpr int NS0 = decltype(ns0c)::value, NS1 = decltype(ns1c)::value;
+      constexpr C2Sched<NS0, NS1, (l2 && HEAD) ? 1 : 0, P1, RD> sch{};
+      // slots: pass 0 = the partner's tiles (pcu, and pcu + 2 / the d x tile), pass 1 = the own ones
+      const int a0 = pcu, a1 = l2 ? pcu + 2 : 2, b0 = cu, b1 = l2 ? cu + 2 : 2;
+      const unsigned char* w00 = wbase + a0 * 1024;
+      const unsigned char* w01 = wbase + a1 * 1024;
+      const unsigned char* w10 = wbase + b0 * 1024;
+      const unsigned char* w11 = wbase + b1 * 1024;
+      asm volatile("" : "+s"(w00), "+s"(w01), "+s"(w10), "+s"(w11));      // opaque per layer: 96 hoisted fragment addresses were spilled
+      bf16x8 b[C2_DEPTH][2];
+      f32x4 acc[2][2];
       unsigned fl = 0;
-      int zoff = 0;
-      asm volatile("" : "+v"(zoff));
-      const gu32* pflag = flags + (layer * CB_G + pcu) * CB_NW + wave;
       u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
-      auto request = [&]() {
-        unsigned spins = 0;
-        while (CF_POLL && fl < (unsigned)ep) {            // (no exit with a request still pending: the compiler would wait
-          if (++spins > SPIN_LIMIT) {                     //  for it -- and with it for the whole ring -- behind the loop)
-            if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+      auto request = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, kk = g % 24;
+        b[g % C2_DEPTH][0] = c2_ring_load((g < 24 ? w00 : w10) + kk * (C2_SLOTS * 1024), lane16);
+        if constexpr ((g < 24 ? NS0 : NS1) == 2) b[g % C2_DEPTH][1] = c2_ring_load((g < 24 ? w01 : w11) + kk * (C2_SLOTS * 1024), lane16);
+      };
+      c4_static_for<RD>([&](auto dc) __attribute__((always_inline)) { request(dc); });
+      c4_static_for<48>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, kk = g % 24, ns = g < 24 ? NS0 : NS1;
+        // ---- side
+        if constexpr (g == 32) {                        // this wave's shipment acknowledged -> its epoch (Guideline 16 R1 per wave)
+          c4_wait_mem(sch.wait_raise());
+          if (lane == 0) __hip_atomic_store(myflag, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (g == 36) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(fl) : "v"(zoff), "s"(pflag) : "memory");
+        if constexpr (g == 40) {
+          c4_wait_reg(sch.wait_flag(), fl);
+          unsigned spins = 0;
+          while (CF_POLL && fl < (unsigned)ep) {        // (no exit with a request still pending: the compiler would wait for it)
+            if (++spins > SPIN_LIMIT) {
+              if (lane == 0) __hip_atomic_fetch_add(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            fl = __hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          __builtin_amdgcn_s_sleep(1);
-          fl = __hip_atomic_load(pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          p0 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my);
+          if constexpr (NS1 == 2) p1 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my + 1024);
         }
-        p0 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my);
-        if (two) p1 = load_sc1_b128(xr, slab + pcu * XSL * 2 + my + 1024);
-      };
-      // (the epoch request goes out through inline asm and is waited for by hand, like the ring: the compiler, which does
-      // not see the ring requests, would wait for vmcnt(0) before the first use of the value)
-      auto side = [&](auto nsc, int i) {
-        if (i == C2_XROUND - 1) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(fl) : "v"(zoff), "s"(pflag) : "memory");
-        if (i == C2_XROUND) {
-          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(fl) : "n"(4 * decltype(nsc)::value));     // younger: one round (4 k-steps) of ring requests
-          request();
+        // ---- request, post, wait, MFMAs
+        if constexpr (g + RD < 48) request(std::integral_constant<int, (g + RD < 48 ? g + RD : 0)>{});
+        if constexpr (g == 47 - RD) fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, 0, 4);
+        if constexpr (C2_KBAR > 0 && g > 0 && g % C2_KBAR == 0) asm volatile("s_barrier" ::: "memory");   // keeps the twelve waves in step
+        if constexpr (ns == 2) c2_wait(sch.wait_frag(g), b[g % C2_DEPTH][0], b[g % C2_DEPTH][1]);
+        else c2_wait(sch.wait_frag(g), b[g % C2_DEPTH][0]);
+        if constexpr (kk == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-      };
-      auto post = [&]() { fetch_part(with_dh{}, nsv, ngs, ncs, ndh, nt, C2_FSPLIT, 4); };
-      constexpr int XR = C2_XROUND < C2_NKK / 4 ? C2_XROUND : -1;
-      if (two) c2_gemm<2, XR, P1>(acc, a_lane, wbase, lane, RSA, s0, s1, pre, [&](int i) { side(std::integral_constant<int, 2>{}, i); }, post);
-      else c2_gemm<1, XR, P1>(acc, a_lane, wbase, lane, RSA, s0, s1, pre, [&](int i) { side(std::integral_constant<int, 1>{}, i); }, post);
-      if (C2_XROUND >= C2_NKK / 4) request();            // (diagnostic builds: no overlap with the GEMM)
-      if (l2) { C2T(6) }
+        bf16x8 af[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[mt] = load_frag<bf16_t>(a_lane + 16 * mt * RSA + 32 * kk);
+#pragma unroll
+        for (int sI = 0; sI < ns; ++sI)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[sI][mt] = mma16(af[mt], b[g % C2_DEPTH][sI], acc[sI][mt]);
+        // ---- tail of pass 0: ship the partner's tiles straight from the accumulators
+        if constexpr (g == 23) {
+          if constexpr (l2) dy_dma(nt);                 // HEAD: the dY rows of the next (earlier) step
+          store_sc1_b128(xr, slab + cu * XSL * 2 + my, pack_acc(acc[0]));
+          if constexpr (NS0 == 2) store_sc1_b128(xr, slab + cu * XSL * 2 + my + 1024, pack_acc(acc[1]));
+        }
+      });
       add_packed(acc[0], p0);
-      scatter(acc[0], s0, layer);
-      if (two) {
+      scatter(acc[0], b0, layer);
+      if constexpr (NS1 == 2) {
         add_packed(acc[1], p1);
-        scatter(acc[1], s1, layer);
+        scatter(acc[1], b1, layer);
       }
-    }
-    if (l2) { C2T(7) }
+    };
+    typedef std::integral_constant<int, 1> one;
+    typedef std::integral_constant<int, 2> two;
+    if (l2) stream(two{}, two{});
+    else if (!xw) stream(one{}, one{});
+    else if (xo == pcu) stream(two{}, one{});
+    else stream(one{}, two{});
     __syncthreads();                                   // the layer's outputs complete in LDS
-    if (l2) { C2T(8) }
   };
 
   auto head_add = [&]() {
@@ -1426,7 +1436,7 @@ constexpr long C4_WFRAG = (long)C4_NKK * C4_G * 1024;       // packed weights of
 //   request of fragment g + 3
 //   wait + the four MFMAs of k-step g
 //   tail(g)   g = 11, 23, 35: ship the finished partner tile (2 stores; g = 11 of layer 2 with the fused head: + 2 dY DMAs)
-// Every wait is vmcnt(M), M = operations issued after the one waited for (c2_gemm's rule); this table holds the counts.
+// Every wait is vmcnt(M), M = operations issued after the one waited for (see c2_ring_load); this table holds the counts.
 #ifndef C4_DEPTH
 #define C4_DEPTH 8                                          // fragment ring of the four-CU kernel: C4_DEPTH - 1 k-steps (1 KB each) requested ahead
 #endif
@@ -1453,38 +1463,6 @@ struct C4Sched {
   constexpr int wait_raise(int q) const { return before[12 * q + 20] - before[12 * q + 12]; }   // since the shipment's last store
   constexpr int wait_flag(int pos_f) const { return before[pos_f + 4] - before[pos_f] - 1; }     // since the epoch request
 };
-
-template <int... I, typename F>
-__device__ __forceinline__ void c4_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void c4_static_for(F&& f) { c4_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-
-// s_waitcnt vmcnt(m) for a compile-time m
-__device__ __forceinline__ void c4_wait_mem(int m) {
-#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (m) {
-    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12) C4_W(13) C4_W(14)
-    C4_W(15) C4_W(16) C4_W(17) C4_W(18) C4_W(19) C4_W(20)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef C4_W
-}
-__device__ __forceinline__ void c4_wait_reg(int m, unsigned& x) {
-#define C4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x)); break;
-  switch (m) {
-    C4_W(0) C4_W(1) C4_W(2) C4_W(3) C4_W(4) C4_W(5) C4_W(6) C4_W(7) C4_W(8) C4_W(9) C4_W(10) C4_W(11) C4_W(12)
-    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); break;
-  }
-#undef C4_W
-}
-// 16 bytes per lane global -> LDS (lds_base + 16 * lane), through inline asm: invisible to the compiler's wait insertion, which
-// would otherwise drain the fragment ring in front of the next LDS read; completion is covered by a later counted wait
-__device__ __forceinline__ void c4_lds_dma16(const void* src_lane, unsigned lds_base /* wave-uniform */) {
-  unsigned keep;
-  const unsigned lb = __builtin_amdgcn_readfirstlane(lds_base);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src_lane), "s"(lb) : "memory");
-}
 
 template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd4_kernel(CoopBwd2Args a) {

@@ -320,7 +320,8 @@ def test_pipelined_update_equals_immediate_update(tmp_path):
     z, meta = load("g2_k5")
     c = meta["config"]
     out = {}
-    for mode in (False, True):
+    modes = [bool(int(m)) for m in os.environ.get("NPPC_TEST_PIPE_MODES", "0,1").split(",")]      # (diagnostic: "0,0" = the same mode twice)
+    for run, mode in enumerate(modes):
         model, wts = build_model(c, "bf16", str(tmp_path))
         cfg = NPPCAudioTrainerConfig(
             nppc_model_configuration=model.config, data_configuration=dict(data_path=".", dataset=dict(clean_path=".", noisy_path=".")),
@@ -342,11 +343,20 @@ def test_pipelined_update_equals_immediate_update(tmp_path):
         tr.flush()
         torch.cuda.synchronize()
         assert tr._pending is None
-        out[mode] = ([float(o) for o in objs], {k: v.detach().clone() for k, v in tr.nppc_model.audio_pc_wrapper.state_dict().items()})
+        out[bool(run)] = ([float(o) for o in objs], {k: v.detach().clone() for k, v in tr.nppc_model.audio_pc_wrapper.state_dict().items()})
         del tr, model
     assert out[False][0] == out[True][0]
-    for k, v in out[False][1].items():
-        assert float((v.float() - out[True][1][k].float()).abs().max()) < 1e-6, k
+    # The weights after three steps agree to the run-to-run noise of the step: a few gradient reductions use fp32 atomics, and Adam
+    # (lr 1e-4) turns their ulp-level order dependence into weight differences of up to a few percent of ONE update where a gradient
+    # is near zero (the real / imaginary branches, whose inputs are divided by a tiny laplace-norm mean).  Two IMMEDIATE runs in one
+    # process differ the same way (NPPC_TEST_PIPE_MODES=0,0: 5.3e-6 / 3.3e-6 on fb_model_imag / _real.fc_output_layer.weight, 1.9e-6
+    # on the attention fc2 weights, 1.2e-6 on two conv1x1 weights, everything else < 1e-6; "1,1" and, depending on what else the
+    # process has allocated, "0,1": 6e-8) -- what runs beside the reductions decides the order of the atomic adds, not the mode.
+    diffs = {k: float((v.float() - out[True][1][k].float()).abs().max()) for k, v in out[False][1].items()}
+    top = sorted(diffs.items(), key=lambda kv: -kv[1])[:6]
+    print("pipelined vs immediate, largest weight differences after 3 steps:", [(k, f"{d:.2e}") for k, d in top])
+    assert top[0][1] < 2e-5, top                                       # a fifth of one Adam step
+    assert sum(d >= 1e-6 for d in diffs.values()) <= 12, top           # ... and only on a handful of the 340 tensors
     w0 = {k: v for k, v in wts.items() if k.startswith("audio_pc_wrapper.")}
     moved = max(float((out[True][1][k[len("audio_pc_wrapper."):]].cpu() - v).abs().max()) for k, v in w0.items())
     assert moved > 1e-4                       # three Adam steps of lr 1e-4 really happened
