@@ -12,7 +12,6 @@
 // packed weights; the weight gradient is nine row-shifted TN GEMMs (tcn.hip) or the exact-f32 kernel below.
 // The concatenations are channel slices of one buffer (producers write with a channel offset).
 #include <algorithm>
-#include <cstdlib>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -991,8 +990,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // rows per workgroup of the BatchNorm column reductions: every workgroup ends with 2*C fp64 atomics on the same
 // addresses, so few large workgroups (about two per CU) beat many small ones (2000 workgroups: the atomics serialise)
 static inline int bn_rows_per_block(long P) {
-  static const long nb = []() { const char* e = getenv("NPPC_BN_BLOCKS"); return e ? atol(e) : 512L; }();   // (A/B switch)
-  long r = (P + nb - 1) / nb;
+  long r = (P + 511) / 512;
   r = (r + 255) / 256 * 256;
   return (int)(r < 1024 ? 1024 : r);
 }
