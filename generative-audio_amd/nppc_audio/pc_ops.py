@@ -89,6 +89,7 @@ class NPPCLoss(torch.autograd.Function):
         ctx.save_for_backward(w, gt, pred, coefA, coefE)
         ctx.lam = float(lam)
         ctx.mark_non_differentiable(err_norm, pr, pi, pm, wn, sm)
+        ctx.set_materialize_grads(False)       # unused outputs arrive as None in backward, not as seven freshly filled zero tensors
         return reconst, objective, err_norm, pr, pi, pm, wn, sm
 
     @staticmethod
@@ -97,6 +98,8 @@ class NPPCLoss(torch.autograd.Function):
         B, K = w.shape[:2]
         N = w[0, 0, 0].numel()
         s = H.stream()
+        if g_rec is None and g_obj is None:
+            return None, None, None, None, None, None
         grec = g_rec.contiguous().float() if g_rec is not None else None
         M1 = torch.empty(B, K + 1, K + 1, 2, dtype=torch.float64, device=w.device)
         if g_obj is None:

@@ -174,6 +174,7 @@ class FlatAdamStepper:
             for p in g["params"]:
                 group_of[id(p)] = g
         self.group = None
+        self._step_t = torch.tensor(0.0)
         for name, p in fp.named:
             g = group_of.get(id(p))
             if g is None:
@@ -189,9 +190,10 @@ class FlatAdamStepper:
                 self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
                 self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
                 self.t = int(st["step"])
-            st["step"] = torch.tensor(float(self.t))
+            st["step"] = self._step_t               # ONE shared host scalar: 340 per-parameter fills per step took 0.7 ms of host time
             st["exp_avg"] = self.m[o:o + k].view(shp)
             st["exp_avg_sq"] = self.v[o:o + k].view(shp)
+        self._step_t.fill_(float(self.t))
 
     def step(self, gflat, grad_scale=1.0, clip=None, poison=None):
         """clip = (device double holding sum(g^2), max_norm): clip_grad_norm_ folded into the same kernel.
@@ -209,8 +211,7 @@ class FlatAdamStepper:
                    float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self.t, float(grad_scale), clip[0],
                    float(clip[1]), H.stream())
         torch.autograd.graph.increment_version(self.eng.fp.flat)   # packed copies of the weights are stale now
-        for _, p in self.eng.fp.named:
-            self.opt.state[p]["step"].fill_(float(self.t))
+        self._step_t.fill_(float(self.t))
 
 
 class NPPCAudioTrainer(nn.Module):
