@@ -93,6 +93,15 @@ __device__ __forceinline__ void coop_prime(typename Frag<T>::type (&pre)[DEPTH -
     }
 }
 
+#ifndef CF_H2_LATE
+#define CF_H2_LATE 1  // forward: the partner's h2 slice is polled / requested behind layer 1's first GEMM (0 = round 3: at the top of the step)
+#endif
+#ifndef CF_APF
+#define CF_APF 1      // 80-row forward: A-operand groups read this many groups ahead of their MFMAs (0 = round 3: read, wait, multiply)
+#endif
+#ifndef CF_AG
+#define CF_AG 1       // row tiles (A fragments) per group
+#endif
 template <typename T, int MT, int RS, int DEPTH, bool PRIMED = false>
 __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /* row n, col 8q of the segment */, int k0, int k1,
                                           int koff /* packed k-step of segment start */, int nk, __amdgpu_buffer_rsrc_t wr, int gp,
@@ -102,6 +111,19 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /
 #pragma unroll
     for (int s = 0; s < 2; ++s) b[s] = BFrag<T>::load(wr, lane, frag_boff<T>(gp, ublk, koff + kk, s, nk));
   };
+  constexpr int AG = CF_AG;
+  [[maybe_unused]] frag an[CF_APF ? CF_APF : 1][AG];   // (MT > 3, CF_APF) the A groups of the next MFMAs, read CF_APF groups ahead
+  if constexpr (MT > 3 && CF_APF != 0) {
+    constexpr int NG0 = (MT + AG - 1) / AG;
+#pragma unroll
+    for (int p = 0; p < CF_APF; ++p)
+#pragma unroll
+      for (int i = 0; i < AG; ++i)
+        if ((p % NG0) * AG + i < MT) {
+          const int kp = k0 + p / NG0 < k1 ? k0 + p / NG0 : k1 - 1;
+          an[p][i] = load_frag<T>(a_lane + 16 * ((p % NG0) * AG + i) * RS + 32 * kp);
+        }
+  }
   auto compute = [&](const frag(&b)[2], int kk) {
     if constexpr (MT <= 3) {
       frag af[MT];
@@ -112,11 +134,40 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mma16(af[mt], b[s], acc[s][mt]);
     } else {
-      constexpr int AG = 2;
-      // many row tiles: A fragments in groups of AG with a scheduling fence in between, so that at most 4*AG (not
-      // 4*MT, twice that when the scheduler hoists the next k-step's reads) VGPRs hold A operands -- the 80-row
+      // many row tiles: A fragments in groups of AG with a scheduling fence in between, so that at most 4*AG*(1 + CF_APF)
+      // (not 4*MT, twice that when the scheduler hoists the next k-step's reads) VGPRs hold A operands -- the 80-row
       // variant spilled its layer-2 cell state otherwise, and ANY scratch reload waits for every outstanding
       // memory operation of the wave (hand-off stores, HBM streams)
+#if CF_APF
+      // round 4: LDS reads run CF_APF groups ahead of their MFMAs (behind the last group of a k-step: the first groups of
+      // the next one): a wave's own matrix work covers part of the LDS latency of its next operands, the other waves of
+      // the SIMD the rest (round 3 issued a group's reads and waited for them right there: three exposed LDS round trips
+      // per k-step and wave)
+      constexpr int NG = (MT + AG - 1) / AG;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        frag nx[AG];
+        const int gt = (g + CF_APF) % NG;
+        int kt = kk + (g + CF_APF) / NG;
+        kt = kt < k1 ? kt : k1 - 1;                                          // (behind the last k-step: harmless re-reads)
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+          if (gt * AG + i < MT) nx[i] = load_frag<T>(a_lane + 16 * (gt * AG + i) * RS + 32 * kt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < AG; ++i)
+            if (g * AG + i < MT) acc[s][g * AG + i] = mma16(an[0][i], b[s], acc[s][g * AG + i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p + 1 < CF_APF; ++p)
+#pragma unroll
+          for (int i = 0; i < AG; ++i) an[p][i] = an[p + 1][i];
+#pragma unroll
+        for (int i = 0; i < AG; ++i) an[CF_APF - 1][i] = nx[i];
+      }
+#else
 #pragma unroll
       for (int m0 = 0; m0 < MT; m0 += AG) {
         frag af[AG];
@@ -130,6 +181,7 @@ __device__ __forceinline__ void coop_gemm(f32x4 (&acc)[2][MT], const T* a_lane /
             if (m0 + i < MT) acc[s][m0 + i] = mma16(af[i], b[s], acc[s][m0 + i]);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
   };
   frag b[DEPTH][2];
@@ -183,6 +235,23 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // LDS row (elements): [X0 (KX) | X1 (KX) | H1 (H) | H2 (H)] + pad.  H = 384 = 12 k-steps.
 // diagnostic phase timers of the forward kernel (tools/diag/stamp_fwd.py builds with -DCF_STAMP)
+// diagnostic builds of the forward kernel (tools/diag/fwd_variants.py; timing only, results are garbage):
+//   CF_NO_CELL  the cell update without its transcendentals (a handful of VALU instructions per cell): what the pointwise
+//               phases cost a step, i.e. what ANY schedule that hides them behind the fragment stream could win at most
+//   CF_NO_BAR   no workgroup barrier inside the time step (the waves of a CU run free): what the step's barriers cost
+//   CF_PRIO=n   static wave priorities: 1 = older waves first (waves 0-3: 3, 4-7: 2, 8-11: 1), 2 = younger waves first
+#ifdef CF_NO_CELL
+#define CF_SIG(x) (0.5f * (x))
+#define CF_TANH(x) (x)
+#else
+#define CF_SIG(x) sigmoid_f(x)
+#define CF_TANH(x) tanh_f(x)
+#endif
+#ifdef CF_NO_BAR
+#define CF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define CF_BARRIER() __syncthreads()
+#endif
 #ifdef CF_STAMP
 #define FT(i) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long nw = __builtin_readcyclecounter(); ft_acc[i] += nw - ft_last; ft_last = nw; }
 #else
@@ -219,6 +288,10 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   int cluster, cu;
   coop_ids(G, cluster, cu);
   if (cluster >= a.clusters) return;
+#ifdef CF_PRIO
+  if (CF_PRIO == 1) { if (wave < 4) __builtin_amdgcn_s_setprio(3); else if (wave < 8) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+  else { if (wave < 4) __builtin_amdgcn_s_setprio(1); else if (wave < 8) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+#endif
   const int ublk = cu * NW + wave;                                // global 16-unit block of this wave
   const int unit_n = ublk * 16 + n;
   const long row0 = (long)cluster * MC;
@@ -305,7 +378,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       store_sc1_b128(xr, base + ch * 16, v);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its write-through stores
-    __syncthreads();
+    CF_BARRIER();
     if (tid == 0) __hip_atomic_store(flags + layer * G + cu, (unsigned)ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // wait for the partners' slices of (layer, epoch) and copy them into LDS
@@ -323,7 +396,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler ordering only: payload loads are sc1
     }
-    __syncthreads();
+    CF_BARRIER();
     const int par = ep & 1;
 #pragma unroll 1
     for (int p = 0; p < G; ++p) {
@@ -366,24 +439,32 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
     const int p = t & 1;
     const int ep = t + 1;
     const size_t ebase = ((size_t)t * N + rbase) * H + unit_n;
-    if (t > 0) {
-      // partners' h2_{t-1} slices: global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`), one row of a slice
-      // (HC bf16 = HC/8 lanes x 16 bytes, landing contiguously at the row's H2 columns) per instruction.  No registers
-      // are held across layer 1 (12 VGPRs per lane before: spilled in the 80-row variant, and a spill store made the
-      // wave wait out the hand-off latency at the top of every step); nobody reads H2 during layer 1, and barrier (1)
-      // drains the DMA (a pending LDS write on the vm counter) long after it landed.
-      wave_poll(1, ep - 1);
-      typedef __attribute__((address_space(3))) void lds_void;
+    // partners' h2_{t-1} slices: global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`), one row of a slice
+    // (HC bf16 = HC/8 lanes x 16 bytes, landing contiguously at the row's H2 columns) per instruction.  No registers
+    // are held across layer 1 (12 VGPRs per lane before: spilled in the 80-row variant, and a spill store made the
+    // wave wait out the hand-off latency at the top of every step); nobody reads H2 during layer 1, and barrier (1)
+    // drains the DMA (a pending LDS write on the vm counter) long after it landed.
+    // Round 4 (CF_H2_LATE): polled and requested BEHIND layer 1's first GEMM, in front of its pointwise phase, instead of
+    // at the top of the step -- a wave's vector-memory operations retire in order, so at the top the first weight
+    // fragments of the step queued behind the poll and the cross-CU read (in-kernel stamps: the step's first GEMM phase
+    // took 15.8k cycles against 7-8k for the other 12-14 k-step phases); here the partner's flag is a third of a step old
+    // and the pointwise phase covers the transfer
+    auto h2_fetch = [&]() {
+      if (t > 0) {
+        wave_poll(1, ep - 1);
+        typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll 1
-      for (int ri = wave; ri < MC * (G - 1); ri += NW) {
-        const int pi = ri / MC, r = ri % MC;
-        const int pr = pi < cu ? pi : pi + 1;
-        if (lane < HC / VEC)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(lds + r * RS + OH2 + pr * HC), 16, lane * 16,
-                                                   ((1 * 2 + ((ep - 1) & 1)) * G + pr) * SLICE * (int)sizeof(T) + r * HC * (int)sizeof(T),
-                                                   0, 16);
+        for (int ri = wave; ri < MC * (G - 1); ri += NW) {
+          const int pi = ri / MC, r = ri % MC;
+          const int pr = pi < cu ? pi : pi + 1;
+          if (lane < HC / VEC)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(lds + r * RS + OH2 + pr * HC), 16, lane * 16,
+                                                     ((1 * 2 + ((ep - 1) & 1)) * G + pr) * SLICE * (int)sizeof(T) + r * HC * (int)sizeof(T),
+                                                     0, 16);
+        }
       }
-    }
+    };
+    if (!CF_H2_LATE) h2_fetch();
     const bool more = t + 1 < a.Tn;
     // x_{t+1} -> the X buffer this step does not read, by LDS-DMA as well (one 128-byte row per instruction,
     // non-temporal: read once).  Issued BEHIND layer 1's GEMMs, in front of its pointwise phase and the two barriers: a
@@ -411,13 +492,14 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt) acc[0][mt] = acc[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + (p ? OX1 : OX0), 0, NKX, 0, nk1, wr1, 0, ublk, lane);
       coop_gemm<T, MT, RS, DEPTH>(acc, a_lane + OH1, 0, NKH, NKX, nk1, wr1, 0, ublk, lane);
+      if (CF_H2_LATE) h2_fetch();
       FT(0)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float iv = sigmoid_f(acc[0][mt][j] + bias(0, 0));
-          const float gv = tanh_f(acc[1][mt][j] + bias(0, 2));
+          const float iv = CF_SIG(acc[0][mt][j] + bias(0, 0));
+          const float gv = CF_TANH(acc[1][mt][j] + bias(0, 2));
           ig[mt][j] = iv * gv;
           if (TRAIN) { iv1[mt][j] = iv; gv1[mt][j] = gv; }
         }
@@ -439,11 +521,11 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float fv = sigmoid_f(acc[0][mt][j] + bias(0, 1));
-          const float ov = sigmoid_f(acc[1][mt][j] + bias(0, 3));
+          const float fv = CF_SIG(acc[0][mt][j] + bias(0, 1));
+          const float ov = CF_SIG(acc[1][mt][j] + bias(0, 3));
           const float cn = fv * c1[mt][j] + ig[mt][j];
           c1[mt][j] = cn;
-          hn1[mt][j] = ov * tanh_f(cn);
+          hn1[mt][j] = ov * CF_TANH(cn);
           if (TRAIN && rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
 #ifndef CF_NO_SAVE
@@ -454,13 +536,13 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         }
     }
     if (PR) coop_prime<T, DEPTH>(pre, NKH, NKH, nk2, wr2, 0, ublk, lane);       // layer 2, pair (i,g), h2 half
-    __syncthreads();                                              // (1) all waves done reading h1_{t-1} and x_t
+    CF_BARRIER();                                              // (1) all waves done reading h1_{t-1} and x_t
     FT(2)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) hw_lane[OH1 + (16 * mt + j) * RS] = from_f32<T>(hn1[mt][j]);
-    __syncthreads();                                              // (2a) own h1_t slice complete in LDS
+    CF_BARRIER();                                              // (2a) own h1_t slice complete in LDS
     FT(3)
     publish(0, OH1, ep);
     FT(4)
@@ -479,7 +561,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       FT(5)
       if (PR) coop_prime<T, DEPTH>(pre, NKH, 0, nk2, wr2, 0, ublk, lane);       // h1 half: in flight during the hand-off
       consume(0, OH1, ep);
-      __syncthreads();                                            // (2c) full h1_t in LDS
+      CF_BARRIER();                                            // (2c) full h1_t in LDS
       FT(6)
       coop_gemm<T, MT, RS, DEPTH, PR>(acc, a_lane + OH1, 0, NKH, 0, nk2, wr2, 0, ublk, lane, pre);
       FT(7)
@@ -487,8 +569,8 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float iv = sigmoid_f(acc[0][mt][j] + bias(1, 0));
-          const float gv = tanh_f(acc[1][mt][j] + bias(1, 2));
+          const float iv = CF_SIG(acc[0][mt][j] + bias(1, 0));
+          const float gv = CF_TANH(acc[1][mt][j] + bias(1, 2));
           ig2[mt][j] = iv * gv;
           if (TRAIN) { iv2[mt][j] = iv; gv2[mt][j] = gv; }
         }
@@ -505,11 +587,11 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float fv = sigmoid_f(acc[0][mt][j] + bias(1, 1));
-          const float ov = sigmoid_f(acc[1][mt][j] + bias(1, 3));
+          const float fv = CF_SIG(acc[0][mt][j] + bias(1, 1));
+          const float ov = CF_SIG(acc[1][mt][j] + bias(1, 3));
           const float cn = fv * c2[mt][j] + ig2[mt][j];
           c2[mt][j] = cn;
-          hn2[mt][j] = ov * tanh_f(cn);
+          hn2[mt][j] = ov * CF_TANH(cn);
           if (rbase + 16 * mt + j < N) {
             const size_t e = ebase + (size_t)(16 * mt + j) * H;
             if (TRAIN) {
@@ -521,13 +603,13 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
           }
         }
     }
-    __syncthreads();                                              // (3) all waves done reading h2_{t-1} / h1_t
+    CF_BARRIER();                                              // (3) all waves done reading h2_{t-1} / h1_t
     FT(10)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) hw_lane[OH2 + (16 * mt + j) * RS] = from_f32<T>(hn2[mt][j]);
-    __syncthreads();                                              // own h2_t slice complete in LDS
+    CF_BARRIER();                                              // own h2_t slice complete in LDS
     FT(11)
     if (more) publish(1, OH2, ep);
     FT(12)

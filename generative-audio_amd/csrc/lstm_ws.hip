@@ -429,7 +429,9 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
       const __amdgpu_buffer_rsrc_t xr = ws_rsrc(a.x, 0, N, WS_KX * 2, true);
 #pragma unroll
       for (int j = 0; j < 12; ++j) st[j] = u32x4{0u, 0u, 0u, 0u};
-      st[12] = __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16, (it.row0 + 8 * ug) * WS_KX * 2, 0);
+      // (the row part of every offset sits in the VECTOR offset: the scalar offset of a raw buffer access is excluded from the
+      // range check, and the rows >= N of a ragged last chunk must read as zeros, not as the next time slot's rows)
+      st[12] = __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + (it.row0 + 8 * ug) * WS_KX * 2, 0, 0);
       stage_write(0);
     }
     f32x16 acc;                                                    // gates of the previous item (cell update pending)
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
 #endif
 #ifndef WS_DIAG_NOGATHER
 #pragma unroll
-        for (int j = 0; j < 12; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ghr, sv[j % 3], gso + (j / 3) * 4 * WS_HB, 16);
-        st[12] = __builtin_amdgcn_raw_buffer_load_b128(gxr, lane * 16, (itn.row0 + 8 * ug) * WS_KX * 2, 0);
+        for (int j = 0; j < 12; ++j) st[j] = __builtin_amdgcn_raw_buffer_load_b128(ghr, sv[j % 3] + gso + (j / 3) * 4 * WS_HB, 0, 16);
+        st[12] = __builtin_amdgcn_raw_buffer_load_b128(gxr, lane * 16 + (itn.row0 + 8 * ug) * WS_KX * 2, 0, 0);
 #else
 #pragma unroll
         for (int j = 0; j < 13; ++j) st[j] = u32x4{(unsigned)gso, 0u, 0u, 0u};
@@ -498,10 +500,11 @@ __global__ __launch_bounds__(WS_NT, 2) void lstm2_ws_fwd_kernel(WsArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 12; ++kk)
           hacc = mma16(*reinterpret_cast<const bf16x8*>(ap + kk * 32), *reinterpret_cast<const bf16x8*>(bp + kk * 64), hacc);
-        float* hp = a.hpart + ((size_t)(it.s - 2) * N + it.row0 + 16 * half + n16) * a.O;
+        const long hrow = it.row0 + 16 * half + n16;               // rows >= N: padding of the last (ragged) chunk
+        float* hp = a.hpart + ((size_t)(it.s - 2) * N + hrow) * a.O;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (4 * q + j < a.O) __builtin_nontemporal_store(hacc[j], hp + 4 * q + j);
+          if (4 * q + j < a.O && hrow < N) __builtin_nontemporal_store(hacc[j], hp + 4 * q + j);
       }
       __builtin_amdgcn_sched_barrier(0);
       // cell state of THIS item (its update runs in the next iteration)
@@ -785,13 +788,15 @@ static int ws_fits(const void* kernel, int smem, int& per_cu_cache, int& n_cu) {
 extern "C" {
 
 // Plan of the weight-stationary forward for N sequences: clusters of 12 CUs and the largest number of 32-sequence chunks
-// one cluster walks; 0 clusters = not applicable (the caller uses the streaming kernels).  Needs whole chunks (N % 32 == 0)
-// and at least 5 chunks per cluster: the flag of item (c, s) is raised two items late and polled two items early, so with
-// fewer chunks a cluster would wait for itself.
+// one cluster walks; 0 clusters = not applicable (the caller uses the streaming kernels).  Needs at least 5 chunks per
+// cluster: the flag of item (c, s) is raised two items late and polled two items early, so with fewer chunks a cluster
+// would wait for itself.  N need not be a multiple of 32 (round 4): the last chunk is ragged -- every access to a row
+// >= N goes through a per-time-slot buffer descriptor of N rows (loads return 0, stores are dropped), the one plain store
+// (the fused head) is guarded.
 int nppc_lstm2_ws_plan(int prec, long N, int H, int I, int n_cu, int* clusters, int* nch_max) {
   *clusters = 0; *nch_max = 0;
-  if (prec != NPPC_PREC_BF16 || H != WS_H || I > WS_KX || N <= 0 || N % WS_MC) return NPPC_OK;
-  const long nchunks = N / WS_MC;
+  if (prec != NPPC_PREC_BF16 || H != WS_H || I > WS_KX || N <= 0) return NPPC_OK;
+  const long nchunks = (N + WS_MC - 1) / WS_MC;
   long cl = n_cu / WS_G;
   if (cl > nchunks / 5) cl = nchunks / 5;
   if (cl < 1) return NPPC_OK;
@@ -827,8 +832,7 @@ int nppc_lstm2_fwd_ws(int train, const void* x, const void* wp1, const void* wp2
     return NPPC_EBADARG;
   if (train && (!g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
   if (whp && (!hpart || O < 1 || O > 16)) return NPPC_EBADARG;
-  if (N % WS_MC) return NPPC_EUNSUPPORTED;
-  const long nchunks = N / WS_MC;
+  const long nchunks = (N + WS_MC - 1) / WS_MC;
   if ((long)clusters * nch_max < nchunks || nchunks / clusters < 5 || N * (long)WS_H * 8 >= (1l << 31)) return NPPC_EBADARG;
   static const int prio = [] { const char* e = getenv("NPPC_WS_PRIO"); return e ? atoi(e) : 0; }();
   WsArgs a{x, wp1, wp2, bias1, bias2, h1, h2, g1, g2, c1, c2, cst, flags, whp, hpart, N, Tn, O, clusters, nch_max, (int)nchunks, prio};

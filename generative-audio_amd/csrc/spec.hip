@@ -169,9 +169,17 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(MapSet ms, const f
 }
 
 // ---------------------------------------------------------------- TSSE backward (direction net: attention weights train)
+// Round 4: NO atomics on this path -- every sum below has ONE writer and a fixed order (samples in index order, maps m in
+// index order), so two runs of the same step give bit-identical attention gradients.
+// Workspace of map j (stride sWs = tsse_ws_stride(B, C, KS) floats, KS = ks0 + ks1 + ks2):
+//   dsg [B][C] | da2 [B][C] | da1 [B][C/2] | pcb [B][3][C] | pcw [B][C*KS] (conv i at column C * (ks_0 + .. + ks_{i-1})) | pf [B][4]
+// pcb / pcw / pf are the per-sample contributions to the conv bias / conv weight / feature_concate_fc (weight x3, bias)
+// gradients; tsse_bwd_outer_kernel adds them up over the samples.
+__host__ __device__ __forceinline__ long tsse_ws_stride(int B, int C, int KS) { return (long)B * (5L * C + C / 2 + (long)C * KS + 4); }
+
 // X0[b][t][coff+c] = x[b][c][t] * ns_b * sg[b][c]  ->  dsg[b][c] = ns_b * sum_t dX0[b][t][coff+c] * x[b][c][t]
-// one workgroup = 64 channels x 64 frames of one sample: x is read along t, dX0 along c (both coalesced), multiplied
-// through an LDS tile; partial sums over the frame chunk go to the ZEROED dsg with one atomic per channel
+// one workgroup = 64 channels x ALL frames of one sample (64-frame chunks through an LDS tile: x is read along t, dX0 along
+// c, both coalesced); thread (cl, tl) sums frames tl + 4 k of every chunk, the four tl partials are added in index order
 // batched: blockIdx.z = b + B * j, j = m*3 + z; dX0 of branch z (stride sY) at column offset m*C; ns [3][nm][B];
 // dsg workspace of map j at j * sWs
 template <typename T>
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ 
                                                           long sY, long sWs, int C, int Tn, int Tp, int ld, int coff) {
   __shared__ float xt[64][65];
   __shared__ float part[4][64];
-  const int j = blockIdx.z / B, b = blockIdx.z % B, c0 = blockIdx.x * 64, t0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int j = blockIdx.z / B, b = blockIdx.z % B, c0 = blockIdx.x * 64, tid = threadIdx.x;
   const float* __restrict__ x = ms.x[j];
   {
     const int z = j % 3, m = j / 3;
@@ -189,25 +197,28 @@ __global__ __launch_bounds__(256) void tsse_bwd_ds_kernel(const T* __restrict__ 
     ns += ((size_t)z * nm + m) * B;
     dsg += (size_t)j * sWs;
   }
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int cc = e / 64, tt = e % 64;
-    xt[cc][tt] = (c0 + cc < C && t0 + tt < Tn) ? x[((size_t)b * C + c0 + cc) * Tn + t0 + tt] : 0.f;
-  }
-  __syncthreads();
   const int cl = tid & 63, tl = tid >> 6;
   float s = 0.f;
-  if (c0 + cl < C) {
-    const T* dp = dX0 + (size_t)b * Tp * ld + coff + c0 + cl;
+  for (int t0 = 0; t0 < Tn; t0 += 64) {
+    __syncthreads();                                   // the previous chunk's tile has been consumed
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int cc = e / 64, tt = e % 64;
+      xt[cc][tt] = (c0 + cc < C && t0 + tt < Tn) ? x[((size_t)b * C + c0 + cc) * Tn + t0 + tt] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + cl < C) {
+      const T* dp = dX0 + (size_t)b * Tp * ld + coff + c0 + cl;
 #pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int tt = tl + 4 * k;
-      if (t0 + tt < Tn) s += to_f32<T>(dp[(size_t)(t0 + tt) * ld]) * xt[cl][tt];
+      for (int k = 0; k < 16; ++k) {
+        const int tt = tl + 4 * k;
+        if (t0 + tt < Tn) s += to_f32<T>(dp[(size_t)(t0 + tt) * ld]) * xt[cl][tt];
+      }
     }
   }
   part[tl][cl] = s;
   __syncthreads();
   if (tid < 64 && c0 + tid < C)
-    atomicAdd(dsg + (size_t)b * C + c0 + tid, ns[b] * (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]));
+    dsg[(size_t)b * C + c0 + tid] = ns[b] * (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]);
 }
 
 struct TsseG {
@@ -216,34 +227,38 @@ struct TsseG {
   float* fcw; float* fcb; float* w1; float* b1; float* w2; float* b2;
 };
 
-// one workgroup per sample: backprop dsg through sigmoid/fc2/relu/fc1/feature_concate_fc/relu/conv-means;
-// parameter gradients are shared by all samples (and by the noisy/enhanced calls) -> fp32 atomics
 __device__ __forceinline__ TsseG tsse_branch_g(TsseG g, long off) {
   for (int i = 0; i < 3; ++i) { g.cw[i] += off; g.cb[i] += off; }
   g.fcw += off; g.fcb += off; g.w1 += off; g.b1 += off; g.w2 += off; g.b2 += off;
   return g;
 }
 
-// batched: blockIdx.y = map j = m*3 + z; workspace of map j: dsg | da2 | da1 at ws + j * sWs
+// one workgroup per (sample, map): backprop dsg through sigmoid/fc2/relu/fc1/feature_concate_fc/relu/conv-means; leaves
+// da2 / da1 (operands of the fc weight gradients) and this sample's contributions pcb / pcw / pf in the workspace
+// batched: blockIdx.y = map j = m*3 + z
 __global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(MapSet ms, const double* __restrict__ rowsum,
-                                                           TsseW w, TsseG g, long sW, int nm, const float* __restrict__ ns_in,
+                                                           TsseW w, long sW, int nm, const float* __restrict__ ns_in,
                                                            const float* __restrict__ pre, const float* __restrict__ sq,
                                                            const float* __restrict__ h1, const float* __restrict__ sg,
                                                            float* __restrict__ ws, long sWs, int C, int C2, int T, int la) {
   __shared__ float da2[TSSE_MAXC];
   __shared__ float da1[TSSE_MAXC / 2];
-  __shared__ float dsq[TSSE_MAXC];
+  __shared__ float wsum[4][16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int B = gridDim.x;
+  const int KS = w.ks[0] + w.ks[1] + w.ks[2];
   const float* __restrict__ x = ms.x[blockIdx.y];
-  const float* __restrict__ dsg = ws + (size_t)blockIdx.y * sWs;
-  float* __restrict__ da2_ws = ws + (size_t)blockIdx.y * sWs + (size_t)B * C;
+  float* __restrict__ wj = ws + (size_t)blockIdx.y * sWs;
+  const float* __restrict__ dsg = wj;
+  float* __restrict__ da2_ws = wj + (size_t)B * C;
   float* __restrict__ da1_ws = da2_ws + (size_t)B * C;
+  float* __restrict__ pcb = da1_ws + (size_t)B * C2 + (size_t)b * 3 * C;
+  float* __restrict__ pcw = da1_ws + (size_t)B * C2 + (size_t)B * 3 * C + (size_t)b * C * KS;
+  float* __restrict__ pf = da1_ws + (size_t)B * C2 + (size_t)B * 3 * C + (size_t)B * C * KS + (size_t)b * 4;
   {
     const int j = blockIdx.y, z = j % 3, m = j / 3;
     const size_t slot = (size_t)z * nm + m;
     w = tsse_branch(w, (long)z * sW);
-    g = tsse_branch_g(g, (long)z * sW);
     rowsum += (size_t)j * B * C;
     ns_in += slot * B;
     pre += slot * B * C * 3;
@@ -272,77 +287,110 @@ __global__ __launch_bounds__(1024) void tsse_bwd_mlp_kernel(MapSet ms, const dou
   for (int c = tid; c < C; c += blockDim.x) {
     float a = 0.f;
     for (int j = 0; j < C2; ++j) a += w.w1[(size_t)j * C + c] * da1[j];
-    dsq[c] = a;
     bsum += a;
     const float* xr = x + ((size_t)b * C + c) * T;
     const double tot = rowsum[(size_t)b * C + c];
+    int koff = 0;
     for (int i = 0; i < 3; ++i) {
       const float pv = pre[((size_t)b * C + c) * 3 + i];
       fsum[i] += a * fmaxf(pv, 0.f);
       const float dp = pv > 0.f ? a * w.fcw[i] : 0.f;
-      if (dp != 0.f) {
-        atomicAdd(g.cb[i] + c, dp);
-        const int ks = w.ks[i];
-        const int Lout = Tp - ks + 1;
-        for (int k = 0; k < ks; ++k) {
+      pcb[i * C + c] = dp;
+      const int ks = w.ks[i];
+      const int Lout = Tp - ks + 1;
+      for (int k = 0; k < ks; ++k) {
+        float v = 0.f;
+        if (dp != 0.f) {
           double prf = 0.0, suf = 0.0;
           for (int t = 0; t < k; ++t) prf += (t < T) ? (double)xr[t] : 0.0;
           for (int m = 0; m < ks - 1 - k; ++m) {
             const int t = Tp - 1 - m;
             suf += (t < T && t >= 0) ? (double)xr[t] : 0.0;
           }
-          atomicAdd(g.cw[i] + c * ks + k, dp * ns * (float)((tot - prf - suf) / Lout));
+          v = dp * ns * (float)((tot - prf - suf) / Lout);
         }
+        pcw[(size_t)C * koff + c * ks + k] = v;
       }
+      koff += ks;
     }
   }
-  for (int i = 0; i < 3; ++i) {
-    const float v = wave_sum(fsum[i]);
-    if ((tid & 63) == 0) atomicAdd(g.fcw + i, v);
+  // feature_concate_fc: the workgroup's sums over the channels, waves added in index order
+  for (int i = 0; i < 4; ++i) {
+    const float v = wave_sum(i < 3 ? fsum[i] : bsum);
+    if ((tid & 63) == 0) wsum[i][tid >> 6] = v;
   }
-  const float v = wave_sum(bsum);
-  if ((tid & 63) == 0) atomicAdd(g.fcb, v);
+  __syncthreads();
+  if (tid < 4) {
+    float v = 0.f;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += wsum[tid][wv];
+    pf[tid] = v;
+  }
 }
 
-// fc weight / bias gradients as batched outer products: one thread per weight element sums over the B samples
-// (one atomic per element per call instead of one per element per sample)
-//   w2[c][j] += sum_b da2[b][c] h1[b][j];  b2[c] += sum_b da2[b][c];  w1[j][c] += sum_b da1[b][j] sq[b][c];  b1[j] += sum_b da1[b][j]
-// batched: blockIdx.y = map j = m*3 + z (both calls m of a branch add into the same gradients)
+// every attention gradient of branch blockIdx.y = z as sums over the samples, ONE thread per element, samples in index
+// order, the nm maps (noisy / enhanced call) of the branch one after the other: G += (sum_b of map 0), G += (sum_b of map 1)
+//   w2[c][j]: sum_b da2[b][c] h1[b][j];  b2[c]: sum_b da2[b][c];  w1[j][c]: sum_b da1[b][j] sq[b][c];  b1[j]: sum_b da1[b][j]
+//   cb_i[c] / cw_i[c][k] / fcw[i] / fcb: sum_b of the per-sample contributions left by tsse_bwd_mlp_kernel
 __global__ __launch_bounds__(256) void tsse_bwd_outer_kernel(const float* __restrict__ ws, long sWs,
                                                              const float* __restrict__ h1, const float* __restrict__ sq, TsseG g,
-                                                             long sW, int nm, int B, int C, int C2) {
-  const float* __restrict__ da2 = ws + (size_t)blockIdx.y * sWs + (size_t)B * C;
-  const float* __restrict__ da1 = da2 + (size_t)B * C;
-  {
-    const int j = blockIdx.y, z = j % 3, m = j / 3;
-    const size_t slot = (size_t)z * nm + m;
-    g = tsse_branch_g(g, (long)z * sW);
-    h1 += slot * B * C2;
-    sq += slot * B * C;
-  }
+                                                             long sW, int nm, int B, int C, int C2, int ks0, int ks1, int ks2,
+                                                             int map0 /* per-map entry point: the map's slot is 0 */) {
+  const int z = blockIdx.y;
+  g = tsse_branch_g(g, (long)z * sW);
+  const int KS = ks0 + ks1 + ks2;
   const int n2 = C * C2;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < n2) {
-    const int c = e / C2, j = e % C2;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + c] * h1[(size_t)b * C2 + j];
-    atomicAdd(g.w2 + e, a);
-  } else if (e < 2 * n2) {
-    const int k = e - n2, j = k / C, c = k % C;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + j] * sq[(size_t)b * C + c];
-    atomicAdd(g.w1 + k, a);
-  } else if (e < 2 * n2 + C) {
-    const int c = e - 2 * n2;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + c];
-    atomicAdd(g.b2 + c, a);
-  } else if (e < 2 * n2 + C + C2) {
-    const int j = e - 2 * n2 - C;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + j];
-    atomicAdd(g.b1 + j, a);
+  const long nW = (long)C * KS;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = 2L * n2 + C + C2 + 3L * C + nW + 4;
+  if (e >= total) return;
+  float* dst;
+  {
+    long k = e;
+    if (k < n2) dst = g.w2 + k;
+    else if ((k -= n2) < n2) dst = g.w1 + k;
+    else if ((k -= n2) < C) dst = g.b2 + k;
+    else if ((k -= C) < C2) dst = g.b1 + k;
+    else if ((k -= C2) < 3L * C) dst = g.cb[k / C] + k % C;
+    else if ((k -= 3L * C) < nW) {
+      if (k < (long)C * ks0) dst = g.cw[0] + k;
+      else if (k < (long)C * (ks0 + ks1)) dst = g.cw[1] + (k - (long)C * ks0);
+      else dst = g.cw[2] + (k - (long)C * (ks0 + ks1));
+    } else { k -= nW; dst = k < 3 ? g.fcw + k : g.fcb; }
   }
+  float acc = *dst;
+  for (int m = 0; m < nm; ++m) {
+    const int j = map0 >= 0 ? map0 : m * 3 + z;
+    const size_t slot = map0 >= 0 ? 0 : (size_t)z * nm + m;
+    const float* __restrict__ da2 = ws + (size_t)j * sWs + (size_t)B * C;
+    const float* __restrict__ da1 = da2 + (size_t)B * C;
+    const float* __restrict__ pcb = da1 + (size_t)B * C2;
+    const float* __restrict__ pcw = pcb + (size_t)B * 3 * C;
+    const float* __restrict__ pf = pcw + (size_t)B * nW;
+    const float* __restrict__ h1m = h1 + slot * B * C2;
+    const float* __restrict__ sqm = sq + slot * B * C;
+    float a = 0.f;
+    long k = e;
+    if (k < n2) {
+      const int c = (int)(k / C2), jj = (int)(k % C2);
+      for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + c] * h1m[(size_t)b * C2 + jj];
+    } else if ((k -= n2) < n2) {
+      const int jj = (int)(k / C), c = (int)(k % C);
+      for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + jj] * sqm[(size_t)b * C + c];
+    } else if ((k -= n2) < C) {
+      for (int b = 0; b < B; ++b) a += da2[(size_t)b * C + k];
+    } else if ((k -= C) < C2) {
+      for (int b = 0; b < B; ++b) a += da1[(size_t)b * C2 + k];
+    } else if ((k -= C2) < 3L * C) {
+      for (int b = 0; b < B; ++b) a += pcb[(size_t)b * 3 * C + k];
+    } else if ((k -= 3L * C) < nW) {
+      for (int b = 0; b < B; ++b) a += pcw[(size_t)b * nW + k];
+    } else {
+      k -= nW;
+      for (int b = 0; b < B; ++b) a += pf[(size_t)b * 4 + k];
+    }
+    acc += a;
+  }
+  *dst = acc;
 }
 
 }  // namespace
@@ -362,10 +410,9 @@ int nppc_tsse_bwd_maps(int prec, const void* dX0, long sY, const float* const* m
   hipStream_t s = (hipStream_t)stream;
   MapSet ms{};
   for (int j = 0; j < nmaps; ++j) { if (!maps[j]) return NPPC_EBADARG; ms.x[j] = maps[j]; }
-  const int nm = nmaps / 3, C2 = C / 2;
-  const long sWs = (long)B * (2 * C + C2);
-  if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)sWs * nmaps, s) != hipSuccess) return NPPC_ELAUNCH;
-  dim3 g1(ceil_div(C, 64), ceil_div(T, 64), B * nmaps);
+  const int nm = nmaps / 3, C2 = C / 2, KS = ks0 + ks1 + ks2;
+  const long sWs = tsse_ws_stride(B, C, KS);
+  dim3 g1(ceil_div(C, 64), 1, B * nmaps);
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, ms, ns, ws, B, nm, sY, sWs, C, T, Tp, ld, 0);
   else
@@ -373,10 +420,11 @@ int nppc_tsse_bwd_maps(int prec, const void* dX0, long sY, const float* const* m
   TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
   TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
   const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
-  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, nmaps), dim3(nt), 0, s, ms, rowsum, w, g, sW, nm, ns, pre, sq, h1, sg, ws, sWs, C,
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, nmaps), dim3(nt), 0, s, ms, rowsum, w, sW, nm, ns, pre, sq, h1, sg, ws, sWs, C,
                      C2, T, look_ahead);
-  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256), nmaps), dim3(256), 0, s, ws, sWs, h1, sq, g, sW,
-                     nm, B, C, C2);
+  const long total = 2L * C * C2 + C + C2 + 3L * C + (long)C * KS + 4;
+  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(total, 256), 3), dim3(256), 0, s, ws, sWs, h1, sq, g, sW, nm, B, C, C2,
+                     ks0, ks1, ks2, -1);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
@@ -421,25 +469,31 @@ int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsu
                   int ld, int coff, void* stream) {
   if (!dX0 || !x || !rowsum || !dsg_ws || B <= 0 || C > TSSE_MAXC) return NPPC_EBADARG;
   hipStream_t s = (hipStream_t)stream;
-  dim3 g1(ceil_div(C, 64), ceil_div(T, 64), B);
-  if (hipMemsetAsync(dsg_ws, 0, sizeof(float) * (size_t)B * C, s) != hipSuccess) return NPPC_ELAUNCH;
+  dim3 g1(ceil_div(C, 64), 1, B);
   MapSet ms{};
   ms.x[0] = x;
-  const long sWs1 = (long)B * (2 * C + C / 2);
+  const int C2 = C / 2, KS = ks0 + ks1 + ks2;
+  const long sWs1 = tsse_ws_stride(B, C, KS);        // dsg_ws: one map's workspace (nppc_tsse_bwd_ws_elems(1, ..))
   if (prec == NPPC_PREC_BF16)
     hipLaunchKernelGGL(tsse_bwd_ds_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dX0, ms, ns, dsg_ws, B, 1, 0L, sWs1, C, T, Tp, ld, coff);
   else
     hipLaunchKernelGGL(tsse_bwd_ds_kernel<float>, g1, dim3(256), 0, s, (const float*)dX0, ms, ns, dsg_ws, B, 1, 0L, sWs1, C, T, Tp, ld, coff);
   TsseW w{{cw0, cw1, cw2}, {nullptr, nullptr, nullptr}, {ks0, ks1, ks2}, fcw, nullptr, w1, nullptr, w2, nullptr};
   TsseG g{{g_cw0, g_cw1, g_cw2}, {g_cb0, g_cb1, g_cb2}, g_fcw, g_fcb, g_w1, g_b1, g_w2, g_b2};
-  // dsg_ws holds B * (2 C + C/2) floats: dsg [B][C] | da2 [B][C] | da1 [B][C/2]
   const int nt = round_up(C, 64) > 1024 ? 1024 : round_up(C, 64);
-  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, 1), dim3(nt), 0, s, ms, rowsum, w, g, 0L, 1, ns, pre, sq, h1, sg, dsg_ws, sWs1,
-                     C, C / 2, T, look_ahead);
-  const int C2 = C / 2;
-  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(2L * C * C2 + C + C2, 256), 1), dim3(256), 0, s, dsg_ws, sWs1, h1, sq, g,
-                     0L, 1, B, C, C2);
+  hipLaunchKernelGGL(tsse_bwd_mlp_kernel, dim3(B, 1), dim3(nt), 0, s, ms, rowsum, w, 0L, 1, ns, pre, sq, h1, sg, dsg_ws, sWs1,
+                     C, C2, T, look_ahead);
+  const long total = 2L * C * C2 + C + C2 + 3L * C + (long)C * KS + 4;
+  hipLaunchKernelGGL(tsse_bwd_outer_kernel, dim3(ceil_div(total, 256), 1), dim3(256), 0, s, dsg_ws, sWs1, h1, sq, g, 0L, 1, B, C, C2,
+                     ks0, ks1, ks2, 0);
   NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+/* floats of workspace nppc_tsse_bwd_maps (nmaps = 3 or 6) / nppc_tsse_bwd (nmaps = 1) need */
+int nppc_tsse_bwd_ws_elems(int nmaps, int B, int C, int ks0, int ks1, int ks2, long* elems) {
+  if (!elems || nmaps < 1 || B < 1 || C < 1) return NPPC_EBADARG;
+  *elems = (long)nmaps * tsse_ws_stride(B, C, ks0 + ks1 + ks2);
   return NPPC_OK;
 }
 

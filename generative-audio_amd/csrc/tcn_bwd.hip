@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ d
 //   m1[t] = gamma1 sum_k wd[k] [0 <= t + (k-1) dil < Tv],   m2[t] = gamma1 sum_k wd[k] xh1[t + (k-1) dil]
 // (the depthwise convolution moved onto the other factor).  So ONE pass yields S1, S2 and the six sums
 // A_j = sum f_j m1, B_j = sum f_j m2, and R1 = A0 - (S1/n) A1 - (S2/n) A2, R2 = B0 - (S1/n) B1 - (S2/n) B2 follow.
-// Per-sample sums: fp64 atomics into S[z][b][8] = (S1, S2, A0, A1, A2, B0, B1, B2); per-channel parameter gradients:
-// LDS partials per workgroup + fp32 atomics, as in the kernels above.
+// Per-sample sums (S1, S2, A0, A1, A2, B0, B1, B2): every channel-group workgroup stores its share in S[z][b][cg][8] (fp64) and
+// the apply pass adds the shares in index order; per-channel parameter gradients: a fixed shuffle / LDS tree per workgroup,
+// one partial row per (branch, sample), summed over the samples by the finishing launch.  No atomics (round 4).
 constexpr int MB_SUMS = 8;
 constexpr int MB_CG = 64;          // channels per workgroup
 constexpr int MB_FL = 32;          // frame lanes per workgroup (256 threads = 32 frame lanes x 8 threads of 8 channels)
@@ -295,7 +296,7 @@ constexpr int MB_PART_ROWS = 9;    // dgamma2, dbeta2 | dgamma1, dbeta1, dbias1,
 struct MidBwdArgs {
   const void* dA; const void* y2; const void* y1;     // [z][B][Tp][C]
   const double* st1; const double* st2;               // GroupNorm (sum, sumsq) per sample: [z][B][2]
-  double* S;                                          // [z][B][8]
+  double* S;                                          // [z][B][Cc/64][8]: per channel group, summed in order by the apply pass
   const float* gamma1; const float* beta1; const float* gamma2; const float* beta2; const float* wd;
   const float* slope1; const float* slope2;
   void* a2;                                           // reduce pass: GN2(y2) for the sconv weight gradient (may be null)
@@ -312,23 +313,33 @@ struct MidBwdArgs {
 __host__ __device__ __forceinline__ size_t mb_part_stride(int Cc) { return (size_t)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG) + 6; }
 
 // per-channel partials of a workgroup: 256 threads -> 64 channels.  acc[r][i] of thread (fl, ct) belongs to channel
-// ct*8 + i of row r: LDS atomics (8 frame lanes of a wave hit the same word), then one plain store per channel
+// ct*8 + i of row r.  No atomics (round 4: LDS float atomics from four waves arrive in any order): the 8 frame lanes of a
+// wave that share a channel are folded with three xor-shuffles (a fixed tree), lanes 0-7 leave the wave's sums in LDS and
+// the four waves are added in index order, one plain store per channel.  sm: [4 waves][ROWS][64] floats.
 template <int ROWS>
-__device__ __forceinline__ void mb_channel_sums(float (&acc)[ROWS][8], float* sm /* [ROWS][64] */, float* dst /* row 0 */, int Cc,
+__device__ __forceinline__ void mb_channel_sums(float (&acc)[ROWS][8], float* sm /* [4][ROWS][64] */, float* dst /* row 0 */, int Cc,
                                                 int c0, int ct) {
-  for (int i = threadIdx.x; i < ROWS * MB_CG; i += 256) sm[i] = 0.f;
-  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();                                     // (sm may still be read by an earlier call)
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&sm[r * MB_CG + ct * 8 + i], acc[r][i]);
+    for (int i = 0; i < 8; ++i) {
+      float v = acc[r][i];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 8) sm[(wave * ROWS + r) * MB_CG + ct * 8 + i] = v;
+    }
   __syncthreads();
-  for (int i = threadIdx.x; i < ROWS * MB_CG; i += 256) dst[(size_t)(i / MB_CG) * Cc + c0 + (i % MB_CG)] = sm[i];
+  for (int i = threadIdx.x; i < ROWS * MB_CG; i += 256)
+    dst[(size_t)(i / MB_CG) * Cc + c0 + (i % MB_CG)] =
+        ((sm[i] + sm[ROWS * MB_CG + i]) + sm[2 * ROWS * MB_CG + i]) + sm[3 * ROWS * MB_CG + i];
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
-  __shared__ float sm[2 * MB_CG];
+  __shared__ float sm[4 * 2 * MB_CG];
   __shared__ double red[MB_SUMS][4];
   const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
   const int ct = threadIdx.x & 7, fl = threadIdx.x >> 3, c0 = blockIdx.x * MB_CG, c8 = c0 + ct * 8;
@@ -401,16 +412,16 @@ __global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
     if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = d;
   }
   __syncthreads();
-  if (threadIdx.x < MB_SUMS)
-    atomicAdd(g.S + (size_t)z * g.sSt * (MB_SUMS / 2) + (size_t)b * MB_SUMS + threadIdx.x,
-              red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x < MB_SUMS)     // this channel group's share of the per-sample sums: one plain store, added up in order by the apply pass
+    g.S[(((size_t)z * gridDim.y + b) * gridDim.x + blockIdx.x) * MB_SUMS + threadIdx.x] =
+        ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
   float* part = g.part + ((size_t)z * gridDim.y + b) * mb_part_stride(Cc);
   mb_channel_sums<2>(ch, sm, part, Cc, c0, ct);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
-  __shared__ float sm[7 * MB_CG];
+  __shared__ float sm[4 * 7 * MB_CG];
   __shared__ float sl[2][4];
   const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
   const int ct = threadIdx.x & 7, fl = threadIdx.x >> 3, c0 = blockIdx.x * MB_CG, c8 = c0 + ct * 8;
@@ -421,7 +432,15 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
   const double cnt = (double)Cc * Tv;
   const GnCtx c1 = gn_ctx(g.st1 + (size_t)z * g.sSt, b, cnt, g.eps);
   const GnCtx c2 = gn_ctx(g.st2 + (size_t)z * g.sSt, b, cnt, g.eps);
-  const double* S = g.S + (size_t)z * g.sSt * (MB_SUMS / 2) + (size_t)b * MB_SUMS;
+  double S[MB_SUMS];             // per-sample sums: the channel groups' shares in index order (no atomics: bit-reproducible)
+  {
+    const double* Sp = g.S + ((size_t)z * gridDim.y + b) * gridDim.x * MB_SUMS;
+#pragma unroll
+    for (int i = 0; i < MB_SUMS; ++i) S[i] = Sp[i];
+    for (int cg = 1; cg < (int)gridDim.x; ++cg)
+#pragma unroll
+      for (int i = 0; i < MB_SUMS; ++i) S[i] += Sp[cg * MB_SUMS + i];
+  }
   const double s1d = S[0] / cnt, s2d = S[1] / cnt;
   const float s1 = (float)s1d, s2 = (float)s2d;
   const float r1 = (float)((S[2] - s1d * S[3] - s2d * S[4]) / cnt), r2 = (float)((S[5] - s1d * S[6] - s2d * S[7]) / cnt);
@@ -503,13 +522,13 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
 }
 
 // sums the per-workgroup partials over the samples and ADDS them to the parameter gradients of branch blockIdx.y.
-// One workgroup = 64 consecutive partial columns x 16 slices of the sample list (256 contiguous bytes per load instruction).
+// One workgroup = 64 consecutive partial columns x 16 slices of the sample list (256 contiguous bytes per load instruction);
+// the two PReLU-slope gradients are columns 9 Cc and 9 Cc + 1, each the sum over (sample, channel group).  Every gradient
+// element has ONE writer and a fixed summation order: no atomics.
 __global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int B, int nb_main) {
   __shared__ float red[16][64];
   const int z = blockIdx.y, Cc = g.Cc;
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  if (blockIdx.x == 0)                                 // the per-sample sums of this launch set are consumed: zero for the next call
-    for (int i = threadIdx.x; i < B * MB_SUMS; i += 1024) g.S[(size_t)z * B * MB_SUMS + i] = 0.0;
   if ((int)blockIdx.x >= nb_main) {                   // workgroups behind the main ones: the sconv bias gradient from tile sums
     const int c = ((int)blockIdx.x - nb_main) * 64 + col;
     float s = 0.f;
@@ -526,12 +545,15 @@ __global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int 
     return;
   }
   const int i = blockIdx.x * 64 + col;
-  const int ncg = Cc / MB_CG, ncols = MB_PART_ROWS * Cc + 2 * ncg;
+  const int ncg = Cc / MB_CG, ncols = MB_PART_ROWS * Cc + 2;
   const size_t ps = mb_part_stride(Cc);
   float s = 0.f;
-  if (i < ncols) {
+  if (i < MB_PART_ROWS * Cc) {
     const float* p = g.part + (size_t)z * B * ps + i;
     for (int b = slice; b < B; b += 16) s += p[(size_t)b * ps];
+  } else if (i < ncols) {                               // slope k = i - 9 Cc: entries (b, cg) at part[b][9 Cc + 2 cg + k]
+    const float* p = g.part + (size_t)z * B * ps + (size_t)MB_PART_ROWS * Cc + (i - MB_PART_ROWS * Cc);
+    for (int e = slice; e < B * ncg; e += 16) s += p[(size_t)(e / ncg) * ps + 2 * (e % ncg)];
   }
   red[slice][col] = s;
   __syncthreads();
@@ -539,8 +561,9 @@ __global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int 
 #pragma unroll
   for (int k = 1; k < 16; ++k) s += red[k][col];
   const size_t zo = (size_t)z * g.sP;
-  if (i >= MB_PART_ROWS * Cc) {                       // PReLU slope partials of the channel groups: a handful of atomics
-    atomicAdd(((i - MB_PART_ROWS * Cc) & 1 ? g.dslope2 : g.dslope1) + zo, s);
+  if (i >= MB_PART_ROWS * Cc) {
+    float* d = ((i - MB_PART_ROWS * Cc) & 1 ? g.dslope2 : g.dslope1) + zo;
+    *d += s;
     return;
   }
   const int row = i / Cc, c = i % Cc;
@@ -605,7 +628,7 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
 
 /* fused backward of a TCNBlock's middle (GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1): dA -> dpre1 and
  * every parameter gradient of those stages plus the conv1x1 bias gradient, one reduce + one apply launch
- * (S: [batch][B][8] fp64 workspace, ZERO on entry -- zero it once after allocation -- and left zero; part: nppc_tcn_mid_bwd_part_elems(...) floats of workspace for the
+ * (S: [batch][B][Cc/64][8] fp64 workspace, no initial state; part: nppc_tcn_mid_bwd_part_elems(...) floats of workspace for the
  * per-workgroup partial sums; a2 (nullable): GN2(y2) written for the sconv weight gradient) */
 int nppc_tcn_mid_bwd_part_elems(int B, int Cc, int Tp, int batch, long* n) {
   if (!n || B <= 0 || Cc <= 0 || Tp <= 0 || batch <= 0) return NPPC_EBADARG;
@@ -626,8 +649,6 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
   if (colpart && (!dbias2 || cp_tiles < 1 || cp_cols < 1 || cp_ld < cp_cols)) return NPPC_EBADARG;
   if (Cc % MB_CG) return NPPC_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  // (S is zero on entry and left zero: the finishing launch clears it behind its last reader -- one memset per block and
-  // step less on the main queue)
   MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
                dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part,
                colpart, cp_tiles, cp_ld, cp_cols, dbias2};
@@ -639,7 +660,7 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, g);
     hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), 0, s, g);
   }
-  const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG), 64);
+  const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2, 64);
   hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(nb_main + (colpart ? (int)ceil_div(cp_cols, 64) : 0), batch), dim3(1024), 0, s, g,
                      B, nb_main);
   NPPC_CHECK_LAUNCH();

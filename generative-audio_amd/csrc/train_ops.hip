@@ -29,37 +29,50 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
   }
 }
 
-// out[c] += sum_r M[r][c]   (fp32 atomics; one partial per block), batched over blockIdx.z
+// out[c] += sum_r M[r][c], batched over blockIdx.z, in two launches and WITHOUT atomics (round 4: float atomics add up in
+// arrival order, so two runs of one step differed in the last bits of these bias gradients): every row block leaves its
+// column sums in part[z][row block][cols] (plain stores), colsum_finish_kernel adds the row blocks in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ M, float* __restrict__ out, int rows, int cols,
-                                                     long ld, long sM, long sOut, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ M, float* __restrict__ part, int rows, int cols,
+                                                     long ld, long sM, int rows_per_block) {
   M += (size_t)blockIdx.z * sM;
-  out += (size_t)blockIdx.z * sOut;
+  part += ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cols;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   if (c >= cols) return;
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += to_f32<T>(M[(size_t)r * ld + c]);
-  atomicAdd(out + c, s);
+  part[c] = s;
+}
+
+// one wave per (column, batch entry): lane l adds row blocks l, l + 64, ... in order, then a fixed xor-shuffle tree
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int cols,
+                                                            long sOut) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, z = blockIdx.y;
+  if (c >= cols) return;
+  const float* p = part + (size_t)z * nblk * cols + c;
+  float s = 0.f;
+  for (int k = lane; k < nblk; k += 64) s += p[(size_t)k * cols];
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)z * sOut + c] += s;
 }
 
 // the same for 16-byte aligned rows padded to a multiple of 8 columns (pad columns are read, never written): a workgroup covers 256 columns (32 lanes x 8 channels, one 16-byte
 // load per lane and row) x CS_ROWS rows (8 row lanes, CS_ROWS / 8 independent loads in flight per thread)
 constexpr int CS_ROWS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ M, float* __restrict__ out, int rows, int cols,
-                                                      long ld, long sM, long sOut, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ M, float* __restrict__ pout, int rows, int cols,
+                                                      long ld, long sM, int rows_per_block) {
   __shared__ float part[8][256 + 8];
   M += (size_t)blockIdx.z * sM;
-  out += (size_t)blockIdx.z * sOut;
+  pout += ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cols;
   const int cl = (threadIdx.x & 31) * 8, c = blockIdx.x * 256 + cl, rl = threadIdx.x >> 5;
   float s[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = 0.f;
   if (c < cols) {
-    // rows_per_block (a multiple of CS_ROWS): tall matrices use few large workgroups -- every workgroup ends with one
-    // atomic per column, and 33 k workgroups adding to the same 64 addresses took 0.8 ms for a 0.07 ms read
+    // rows_per_block (a multiple of CS_ROWS): tall matrices use few large workgroups (one partial row per workgroup)
     for (int rb = blockIdx.y * rows_per_block; rb < (blockIdx.y + 1) * rows_per_block && rb < rows; rb += CS_ROWS) {
 #pragma unroll
       for (int j = 0; j < CS_ROWS / 8; ++j) {
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const T* __restrict__ M, f
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
-    atomicAdd(out + cc, t);
+    pout[cc] = t;
   }
 }
 
@@ -397,29 +410,52 @@ int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long
   return NPPC_OK;
 }
 
-int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
-                void* stream) {
-  if (!M || !out || rows <= 0 || cols <= 0) return NPPC_EBADARG;
-  hipStream_t s = (hipStream_t)stream;
+// row blocking of nppc_colsum: (aligned 16-byte path?, rows per block, row blocks)
+static void colsum_plan(int prec, const void* M, int rows, int cols, long ld, long sM, bool& vec8, int& rpb, int& nblk) {
   const size_t esz = prec == NPPC_PREC_BF16 ? 2 : 4;
-  if (ld >= (long)round_up(cols, 8) && ld % 8 == 0 && sM % 8 == 0 && ((uintptr_t)M) % 16 == 0 && (ld * esz) % 16 == 0) {
+  vec8 = ld >= (long)round_up(cols, 8) && ld % 8 == 0 && sM % 8 == 0 && ((uintptr_t)M) % 16 == 0 && (ld * esz) % 16 == 0;
+  if (vec8) {
     const int colblk = ceil_div(cols, 256);
-    int rpb = CS_ROWS;                                     // aim at <= ~1024 workgroups per batch entry
+    rpb = CS_ROWS;                                         // aim at <= ~1024 workgroups per batch entry
     while ((long)ceil_div(rows, rpb) * colblk > 1024) rpb *= 2;
-    dim3 grid(colblk, ceil_div(rows, rpb), batch);
-    if (prec == NPPC_PREC_BF16)
-      hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, out, rows, cols, ld, sM, sOut, rpb);
-    else
-      hipLaunchKernelGGL(colsum8_kernel<float>, grid, dim3(256), 0, s, (const float*)M, out, rows, cols, ld, sM, sOut, rpb);
-    NPPC_CHECK_LAUNCH();
-    return NPPC_OK;
+  } else {
+    rpb = 128;
+    while (ceil_div(rows, rpb) > 4096) rpb *= 2;
   }
-  const int rpb = 128;
-  dim3 grid(ceil_div(cols, 256), ceil_div(rows, rpb), batch);
-  if (prec == NPPC_PREC_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, out, rows, cols, ld, sM, sOut, rpb);
-  else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)M, out, rows, cols, ld, sM, sOut, rpb);
+  nblk = ceil_div(rows, rpb);
+}
+
+/* floats of scratch nppc_colsum needs (an upper bound that does not depend on the alignment of M) */
+int nppc_colsum_scratch_elems(int rows, int cols, int batch, long* n) {
+  if (!n || rows <= 0 || cols <= 0 || batch <= 0) return NPPC_EBADARG;
+  int nb8 = CS_ROWS, nb1 = 128;
+  while ((long)ceil_div(rows, nb8) * ceil_div(cols, 256) > 1024) nb8 *= 2;
+  while (ceil_div(rows, nb1) > 4096) nb1 *= 2;
+  const long a = ceil_div(rows, nb8), b = ceil_div(rows, nb1);
+  *n = (long)batch * (a > b ? a : b) * cols;
+  return NPPC_OK;
+}
+
+int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
+                float* scratch, long scratch_elems, void* stream) {
+  if (!M || !out || !scratch || rows <= 0 || cols <= 0 || batch <= 0) return NPPC_EBADARG;
+  hipStream_t s = (hipStream_t)stream;
+  bool vec8; int rpb, nblk;
+  colsum_plan(prec, M, rows, cols, ld, sM, vec8, rpb, nblk);
+  if (scratch_elems < (long)batch * nblk * cols) return NPPC_EBADARG;
+  dim3 grid(ceil_div(cols, 256), nblk, batch);
+  if (vec8) {
+    if (prec == NPPC_PREC_BF16)
+      hipLaunchKernelGGL(colsum8_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, scratch, rows, cols, ld, sM, rpb);
+    else
+      hipLaunchKernelGGL(colsum8_kernel<float>, grid, dim3(256), 0, s, (const float*)M, scratch, rows, cols, ld, sM, rpb);
+  } else {
+    if (prec == NPPC_PREC_BF16)
+      hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)M, scratch, rows, cols, ld, sM, rpb);
+    else
+      hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)M, scratch, rows, cols, ld, sM, rpb);
+  }
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 4), batch), dim3(256), 0, s, scratch, out, nblk, cols, sOut);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

@@ -152,7 +152,8 @@ SIGS = {
     "nppc_loss_bwd_coef": [P, P, P, F, F, P, I, I, P],
     "nppc_loss_bwd_coef_dev": [P, P, P, P, F, F, P, I, I, P],
     "nppc_transpose": [I, P, P, I, I, L, L, L, L, I, I, P],
-    "nppc_colsum": [I, P, P, I, I, L, L, L, I, P],
+    "nppc_colsum": [I, P, P, I, I, L, L, L, I, P, L, P],
+    "nppc_colsum_scratch_elems": [I, I, I, PL],
     "nppc_sb_head_bwd": [I, P, P, P, P, P, P, L, I, I, I, I, I, P],
     "nppc_subband_stage_bwd": [I, P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, P],
     "nppc_reduce_slabs": [P, I, L, L, P, L, I, I, I, I, I, L, L, I, P],
@@ -198,6 +199,7 @@ SIGS = {
     "nppc_unet_out_bwd": [I, P, L, P, P, L, I, I, I, I, P],
     "nppc_tcn_gn_bwd": [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, L, L, L, I, P],
     "nppc_tcn_dwconv_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, L, L, L, I, P],
+    "nppc_tsse_bwd_ws_elems": [I, I, I, I, I, I, PL],
     "nppc_tsse_bwd": [I, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                       I, I, I, I, I, I, I, P],
 }
@@ -223,3 +225,12 @@ def call(name, *args):
     check(fn(*conv), name)
     e1.record()
     PROFILE.append((name, e0, e1))
+
+
+def colsum(prec, M, out, rows, cols, ld, sM, sOut, batch, scratch_for, s):
+    """nppc_colsum with its scratch: scratch_for(n_floats) -> a float32 device tensor owned by the caller (one per
+    concurrently running call)"""
+    n = ctypes.c_long()
+    call("nppc_colsum_scratch_elems", rows, cols, batch, ctypes.byref(n))
+    sc = scratch_for(n.value)
+    call("nppc_colsum", prec, M, out, rows, cols, ld, sM, sOut, batch, sc, sc.numel(), s)

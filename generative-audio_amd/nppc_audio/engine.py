@@ -5,6 +5,7 @@ one net (the frozen restorer: 3 input maps; the direction net: 6 maps, 2K output
 FullSubNet_Plus.forward (FullSubNet_plus/.../fullsubnet_plus.py:143-230) and
 MultiDirectionFullSubNet_Plus.forward (nppc_audio/networks.py:63-163) stage by stage.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -479,7 +480,8 @@ class FSNEngine:
                 rows = (Rr + 64 * S - 1) // (64 * S) * (64 * S)
                 H.call("nppc_gemm_tn_splitk", h2_rows, Hd, dyt_rows, 16, slab, 64, Hd, 64, rows, S, s)
                 H.call("nppc_reduce_slabs_t", slab, S, Hd * 64, 64, self.g("sb_model.fc_output_layer.weight"), Hd, O, Hd, 0, 0, 1, s)
-                H.call("nppc_colsum", self.prec, dyt_rows, self.g("sb_model.fc_output_layer.bias"), Rr, O, 16, 0, 0, 1, s)
+                H.colsum(self.prec, dyt_rows, self.g("sb_model.fc_output_layer.bias"), Rr, O, 16, 0, 0, 1,
+                         lambda n: ws("cs_head", (n,), torch.float32), s)
             return
         # generic path (fp32 parity mode, small hidden sizes): transposed copies + the NT split-K GEMM
         bk = 64 if self.prec == H.PREC_BF16 else 32
@@ -600,7 +602,8 @@ class FSNEngine:
             # parameter gradients only (bias: column sums; weight: two transposes + the NT split-K product -- F and C are not
             # multiples of the TN kernel's tiles)
             q = H.stream()
-            H.call("nppc_colsum", prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3, q)
+            H.colsum(prec, dpre_fb, self.g("fb_model.fc_output_layer.bias"), R, F, ldF, R * ldF, sP, 3,
+                     lambda n: ws("cs_fc", (n,), torch.float32), q)
             H.call("nppc_transpose", prec, dpre_fb, tA, R, F, ldF, R, R * ldF, sTA, 0, 3, q)
             H.call("nppc_transpose", prec, X8, tB, R, ldC, ldC, R, R * ldC, sTB, 1, 3, q)
             self._wgrad(tA, R, sTA, tB, R, sTB, Fr, ldC, R, S2, "fb_model.fc_output_layer.weight", C, F, C, slab, batch=3, sDst=sP)
@@ -642,7 +645,7 @@ class FSNEngine:
         sAct = B * Tp * TCN_HIDDEN
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
-        Smid = ws("Smid", (3, B, 8), torch.float64, zero=True)      # zero on entry, left zero by every call
+        Smid = ws("Smid", (3, B, TCN_HIDDEN // 64, 8), torch.float64)      # channel-group shares of the per-sample sums
         Pmid = ws("Pmid", (H.mid_bwd_part_elems(B, TCN_HIDDEN, Tp, 3),), torch.float32)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):
@@ -655,7 +658,8 @@ class FSNEngine:
             else:
                 a2 = d["a2"]
             if not cs_ok:
-                H.call("nppc_colsum", prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3, s)
+                H.colsum(prec, dXo, self.g(pre + "sconv.bias"), R, C, ldC, R * ldC, sP, 3,
+                         lambda n: ws("cs_sconv", (n,), torch.float32), s)
             # dA2 = dXo W2  (gradient of the normalised depthwise output)
             H.call("nppc_gemm_nt", prec, EPI_PLAIN, dXo, ldC, R * ldC, self.W2T[i], ldC, TCN_HIDDEN * ldC, h1b, TCN_HIDDEN,
                    sAct, None, 0, None, 0, 0, None, 0, None, 0, R, TCN_HIDDEN, ldC, Tp, Tv, TCN_HIDDEN, 0, 3, 1, s)
@@ -719,7 +723,9 @@ class FSNEngine:
             dXo = dXL[0]
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)
         sv = d["tsse_saved"]
-        dsg = ws("dsg", (3 * self.nm * B * (2 * F + F // 2),), torch.float32)      # per map: dsg | da2 | da1 (csrc/spec.hip)
+        n_ws = ctypes.c_long()
+        H.call("nppc_tsse_bwd_ws_elems", 3 * self.nm, B, F, self.ks[0], self.ks[1], self.ks[2], ctypes.byref(n_ws))
+        dsg = ws("dsg", (n_ws.value,), torch.float32)      # per map: dsg | da2 | da1 | per-sample contributions (csrc/spec.hip)
         att = "channel_attention."
         H.call("nppc_tsse_bwd_maps", prec, dXo, R * ldC, H.ptr_array(d["maps"]), 3 * self.nm, d["rs"],
                self.p(att + "smallConv1d.0.weight"), self.p(att + "middleConv1d.0.weight"), self.p(att + "largeConv1d.0.weight"),

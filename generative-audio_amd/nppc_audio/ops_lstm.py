@@ -70,7 +70,11 @@ COOP = True          # use the cooperative (weights split over CU pairs) kernels
 # the restorer launch takes 8.9 ms against 9.8 ms for the CU-pair kernel and the no-grad direction launch 4.4 against 5.6,
 # but INSIDE the train step the same launches are slower (9.3 vs 9.1 ms) and so are the launches behind them: these kernels
 # are bound by what the chip may draw, and the cluster kernel's hidden-state gather (4.3 TB/s from L2) costs 20 % of its clock
-WS_MODE = os.environ.get("NPPC_LSTM_WS", "0")
+# Round 4 default "auto": the cluster kernel takes the INFERENCE launches of small problems -- those for which the streaming
+# plan falls back to four-CU clusters because CU pairs would leave most of the chip idle (BASELINE config 5: 2056 sequences
+# x 1878 steps: 23.4 ms against 48.3 ms for the four-CU streaming plan, step 145.3 -> 120.1 ms; the training forward at
+# N = 1024 stays on the streaming kernel: 35.4 vs 32.9 ms; profiles/r04_bench_c5_ws_modes.txt)
+WS_MODE = os.environ.get("NPPC_LSTM_WS", "auto")
 WS = WS_MODE != "0"
 N_CU = None
 
@@ -208,7 +212,7 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         out["c2"] = workspace(tag + ("c2",), (Tn, N, Hd), dt, dev)
         out["g1"] = workspace(tag + ("g1",), (Tn, N, Hd, 4), dt, dev)
         out["g2"] = workspace(tag + ("g2",), (Tn, N, Hd, 4), dt, dev)
-    if mtile == "ws" or (WS and COOP and mtile is None and (not train or WS_MODE == "2")):
+    if mtile == "ws" or (WS and COOP and mtile is None and (not train or WS_MODE == "2") and _ws_wanted(N, packed, train)):
         ws_out = _lstm2_forward_ws(x_tm, packed, train, head, out, tag)
         if ws_out is not None:
             return ws_out
@@ -252,6 +256,15 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
         H.stream()))
     return out
+
+
+def _ws_wanted(N, packed, train):
+    """NPPC_LSTM_WS=1|2: whenever the plan applies; "auto": only where the streaming plan would not be CU pairs"""
+    if WS_MODE != "auto":
+        return True
+    G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    H.call("nppc_lstm2_coop_plan", packed.prec, int(train), N, packed.Hd, _n_cu(), ctypes.byref(G), ctypes.byref(cmt), ctypes.byref(ncl))
+    return ncl.value > 0 and G.value >= 4
 
 
 def ws_plan(N, packed):

@@ -380,7 +380,8 @@ class UNetEngine:
         d_rawo = self.buf("d_rawo", 0, OUT_LD)
         H.call("nppc_unet_out_bwd", self.prec, dout, dout_pstride, self.saved["mask"], d_rawo.t, OUT_LD, K, B, F, T, s)
         bias_acc = torch.zeros(OUT_LD, dtype=torch.float32, device=self.dev)
-        H.call("nppc_colsum", self.prec, d_rawo.t, bias_acc, self.P[0], OUT_LD, OUT_LD, 0, 0, 1, s)
+        H.colsum(self.prec, d_rawo.t, bias_acc, self.P[0], OUT_LD, OUT_LD, 0, 0, 1,
+                 lambda n: torch.empty(n, dtype=torch.float32, device=self.dev), s)
         self.g("outc.conv.bias").copy_(bias_acc[:K])
         self._wgrad("outc.conv", 64, K, 1, d_rawo.t, OUT_LD, self.saved["u4"], 64, 0)
         d_u = self.buf("d_u", 0, 64)

@@ -50,7 +50,10 @@ int nppc_tsse_fwd_maps(int prec, const float* const* maps, int nmaps, double* ro
                        const float* fcw, const float* fcb, const float* w1, const float* b1, const float* w2, const float* b2, long sW,
                        float* scale, float* ns, float* pre, float* sq, float* h1, float* sg, void* X0, long sY, int B, int C, int T,
                        int look_ahead, int Tp, int ld, void* stream);
-/* ... and its backward (parameter gradients only: the maps are data), four launches; ws: nmaps * B * (2 C + C/2) floats */
+/* ... and its backward (parameter gradients only: the maps are data), three launches, NO atomics: every gradient element
+ * has one writer and a fixed summation order (samples, then maps, in index order), so repeated runs are bit-identical.
+ * ws: nppc_tsse_bwd_ws_elems(nmaps, ..) floats (per map: dsg | da2 | da1 | per-sample conv / fc contributions) */
+int nppc_tsse_bwd_ws_elems(int nmaps, int B, int C, int ks0, int ks1, int ks2, long* elems);
 int nppc_tsse_bwd_maps(int prec, const void* dX0, long sY, const float* const* maps, int nmaps, const double* rowsum,
                        const float* cw0, const float* cw1, const float* cw2, int ks0, int ks1, int ks2, const float* fcw,
                        const float* w1, const float* w2, long sW, const float* ns, const float* pre, const float* sq,
@@ -64,7 +67,7 @@ int nppc_tsse_fwd(const float* x, const double* rowsum, const float* cw0, const 
                   void* stream);
 int nppc_tsse_bwd(int prec, const void* dX0, const float* x, const double* rowsum, const float* cw0, const float* cw1,
                   const float* cw2, int ks0, int ks1, int ks2, const float* fcw, const float* w1, const float* w2,
-                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws, /* B*(2C + C/2) floats */
+                  const float* ns, const float* pre, const float* sq, const float* h1, const float* sg, float* dsg_ws, /* nppc_tsse_bwd_ws_elems(1, ..) floats */
                   float* g_cw0, float* g_cb0, float* g_cw1, float* g_cb1, float* g_cw2, float* g_cb2, float* g_fcw,
                   float* g_fcb, float* g_w1, float* g_b1, float* g_w2, float* g_b2, int B, int C, int T, int look_ahead, int Tp,
                   int ld, int coff, void* stream);
@@ -123,9 +126,9 @@ int nppc_tcn_dwconv_bwd(int prec, const void* du, const void* y1, const double* 
 /* fused backward of a TCNBlock's middle (causal_conv.py:98-106 in reverse: GroupNorm-2, PReLU-2, depthwise dilated conv,
  * GroupNorm-1, PReLU-1): dA = gradient of GN2's output -> dpre1 = gradient of conv1x1's output, every parameter gradient of
  * those stages and the conv1x1 bias gradient, in ONE reduce + ONE apply launch (csrc/tcn_bwd.hip).  y1 / y2: the saved PReLU
- * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][8] fp64 workspace, ZERO on entry (zero it once after allocation; the call leaves it zero); part:
+ * outputs, st1 / st2 their GroupNorm (sum, sumsq); S: [batch][B][Cc/64][8] fp64 workspace for the channel groups' shares of the per-sample sums (no initial state; no atomics: the apply pass adds the shares in index order); part:
  * nppc_tcn_mid_bwd_part_elems(B, Cc, Tp, batch, &n) -> n floats of workspace for per-workgroup partial sums (a third, tiny launch adds
- * them to the gradients: no contended global atomics); a2 (nullable) receives GN2(y2), the operand of the sconv weight
+ * them to the gradients in a fixed order: no atomics anywhere, repeated runs are bit-identical); a2 (nullable) receives GN2(y2), the operand of the sconv weight
  * gradient.  Gradients are ACCUMULATED into their destinations.  colpart (nullable): the tile column sums that
  * nppc_gemm_nt_colsum left for the block's upstream gradient, [batch][cp_tiles][cp_ld] -> the finishing launch also writes the
  * sconv bias gradient dbias2[z*sP + c] = sum over the tiles, c < cp_cols (sconv.bias: causal_conv.py:107). */
@@ -156,8 +159,12 @@ int nppc_tcn_pack_sconv(int prec, const float* W, const float* gamma, const floa
                         long dst_stride_a, long dst_stride_b, void* stream);
 int nppc_transpose(int prec, const void* in, void* out, int rows, int cols, long ld_in, long ld_out, long sIn, long sOut,
                    int relu, int batch, void* stream);
+/* out[z][c] += sum_r M[z][r][c] (bias gradients), two launches, NO atomics: row blocks leave partial sums in `scratch`
+ * (nppc_colsum_scratch_elems floats, caller-owned: one scratch per concurrently running call) and a finishing launch adds them
+ * in a fixed order, so repeated runs are bit-identical */
+int nppc_colsum_scratch_elems(int rows, int cols, int batch, long* n);
 int nppc_colsum(int prec, const void* M, float* out, int rows, int cols, long ld, long sM, long sOut, int batch,
-                void* stream);
+                float* scratch, long scratch_elems, void* stream);
 int nppc_reduce_slabs_t(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int ncols,
                         long sSlab, long sDst, int batch, void* stream);
 int nppc_reduce_slabs(const float* slabs, int S, long slab_stride, long ld, float* dst, long dst_ld, int rows, int col0,
@@ -211,7 +218,7 @@ int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, cons
                              float* hpart, int O, void* stream);
 int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
                           void* stream);
-/* Weight-STATIONARY forward of the same LSTM (sequence_model.py:113-123; bf16, H = 384, I <= 64, N % 32 == 0): clusters of
+/* Weight-STATIONARY forward of the same LSTM (sequence_model.py:113-123; bf16, H = 384, I <= 64; any N, the last 32-sequence chunk may be ragged): clusters of
  * 12 CUs keep all weights in registers for the whole launch and exchange the hidden state instead (csrc/lstm_ws.hip).
  * nppc_lstm2_ws_plan: clusters == 0 -> not applicable.  wp1 / wp2: nppc_lstm2_ws_pack of the fp32 weights.
  * train = 0: h1 / h2 are [2][N][H] exchange rings and g / c may be null; train = 1: the saved state of nppc_lstm2_fwd

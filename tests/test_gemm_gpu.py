@@ -56,11 +56,18 @@ def test_colsum_variants_match_torch(rows, cols, ld, batch, prec):
     M = torch.zeros(batch, rows, ld, dtype=dt, device="cuda")
     M[:, :, :cols] = torch.randn(batch, rows, cols, generator=g).to(dt).cuda()
     out = torch.full((batch, cols + 3), 0.5, dtype=torch.float32, device="cuda")      # accumulates; neighbours untouched
-    H.call("nppc_colsum", prec, M, out, rows, cols, ld, rows * ld, cols + 3, batch, H.stream())
+    scratch = lambda n: torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+    H.colsum(prec, M, out, rows, cols, ld, rows * ld, cols + 3, batch, scratch, H.stream())
     want = M[:, :, :cols].double().sum(dim=1).cpu() + 0.5
     got = out.cpu().double()
     assert float((got[:, :cols] - want).abs().max()) < 2e-4 * (rows ** 0.5) + 1e-3
     assert float((got[:, cols:] - 0.5).abs().max()) == 0.0
+    # no atomics: a second launch reproduces the first bit for bit
+    out2 = torch.full_like(out, 0.5)
+    H.colsum(prec, M, out2, rows, cols, ld, rows * ld, cols + 3, batch, scratch, H.stream())
+    assert torch.equal(out, out2)
+    with pytest.raises(RuntimeError, match="bad argument"):            # a scratch that is too small is refused, not overrun
+        H.call("nppc_colsum", prec, M, out2, rows, cols, ld, rows * ld, cols + 3, batch, torch.empty(1, device="cuda"), 1, H.stream())
 
 
 def test_pack_matrix_batched_equals_per_matrix_packs():

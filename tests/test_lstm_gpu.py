@@ -477,7 +477,9 @@ def test_handoff_timeout_counter_is_sticky():
 
 
 @pytest.mark.parametrize("N,Tn,train,O", [(160, 9, False, 2), (320, 7, True, 10), (512, 6, False, 4), (512, 5, True, 16),
-                                          (1280, 5, True, 10), (3360, 4, False, 2)])
+                                          (1280, 5, True, 10), (3360, 4, False, 2),
+                                          # ragged last chunk (N % 32 != 0, round 4): rows >= N read zeros and are never stored
+                                          (514, 6, False, 2), (1030, 5, True, 16), (2056, 4, False, 2)])
 def test_weight_stationary_forward_matches_single_workgroup_kernel_and_oracle(N, Tn, train, O):
     """The 12-CU weight-stationary cluster kernel (csrc/lstm_ws.hip: weights in registers, one fused hand-off per time step,
     chunks of 32 sequences walked round robin; 1, 2, 3 (ragged: 6/5/5 chunks), 8 and 21 clusters) against the single-workgroup

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     mk = lambda: (torch.randn(Z, B, Tp, C, generator=g) * 0.5).to(dt).cuda()
     dA, y2, y1 = mk(), mk(), mk()
     st = torch.zeros(Z, B, 2, dtype=torch.float64, device="cuda"); st[..., 1] = C * Tv * 0.3
-    S = torch.empty(Z, B, 8, dtype=torch.float64, device="cuda")
+    S = torch.empty(Z, B, C // 64, 8, dtype=torch.float64, device="cuda")
     part = torch.empty(H.mid_bwd_part_elems(B, C, Tp, Z), device="cuda")
     sP = 1 << 20
     par = lambda: torch.rand(Z * sP, device="cuda") * 0.5 + 0.25
