@@ -53,6 +53,8 @@ struct CoopArgs {
   // fused output head (inference): whp [16][H] row-major (rows >= O zero), hpart [G][Tn][N][O] fp32 partial sums of
   // sum_u h2[t][n][u] * Wh[o][u] over the units of CU g; whp == nullptr: h2 is stored instead
   const void* whp; float* hpart; int O;
+  int x_ld;           // row stride of x in elements: KX, or a packed width (multiple of 8, >= I + 1): only the first x_ld columns of a
+                      // row are fetched, the LDS columns behind them stay zero (round 4: the frozen restorer's input at 40 columns)
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -322,15 +324,15 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
   for (int mt = 0; mt < MT; ++mt) c1[mt] = c2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const T* xg = reinterpret_cast<const T*>(a.x);
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.Tn * N * KX * sizeof(T)));
-  constexpr int cpr = KX / VEC, nchunk = MC * cpr;
-  constexpr int XCH = (nchunk + NT - 1) / NT;
+  const int xld = a.x_ld;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.Tn * N * xld * sizeof(T)));
+  const int cpr = xld / VEC;                                      // 16-byte chunks fetched per row (<= KX / VEC)
   __syncthreads();
-  for (int ch = tid; ch < nchunk; ch += NT) {
+  for (int ch = tid; ch < MC * cpr; ch += NT) {
     const int r = ch / cpr, cc = ch % cpr;
     if (row0 + r < N)
       *reinterpret_cast<uint4*>(lds + r * RS + OX0 + cc * VEC) =
-          *reinterpret_cast<const uint4*>(xg + ((size_t)(row0 + r)) * KX + cc * VEC);
+          *reinterpret_cast<const uint4*>(xg + ((size_t)(row0 + r)) * xld + cc * VEC);
   }
   __syncthreads();
 
@@ -478,7 +480,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
         for (int r = wave; r < MC; r += NW)
           if (row0 + r < N && lane < cpr)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(lds + r * RS + (p ? OX0 : OX1)), 16, lane * 16,
-                                                     (int)((((size_t)(t + 1) * N + row0 + r) * KX) * sizeof(T)), 0, 2);
+                                                     (int)((((size_t)(t + 1) * N + row0 + r) * xld) * sizeof(T)), 0, 2);
       }
     };
     constexpr bool PR = MT <= 2;                                   // prime the next weight segment across sync points
@@ -1302,8 +1304,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) 
     if constexpr (HEAD) {
       typedef __attribute__((address_space(3))) void lds_void;
       const int tcl = tau > 0 ? tau : 0;
-      c4_lds_dma16(reinterpret_cast<const unsigned char*>(a.dyt) + (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16,
-                   (unsigned)(unsigned long)(lds_void*)dys);
+      // per-lane clamp to the last 16 bytes of dyt [Tn][N][16]: the rows past N of a ragged last cluster are garbage
+      // that nothing uses (their gate gradients are zeroed), but at the last time step they lie BEHIND the tensor -- an
+      // exact-size dyt at the end of a memory segment faulted here (round 4, tests/test_lstm_gpu.py)
+      size_t off = (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16;
+      const size_t last = (size_t)a.Tn * N * 16 * sizeof(T) - 16;
+      off = off < last ? off : last;
+      c4_lds_dma16(reinterpret_cast<const unsigned char*>(a.dyt) + off, (unsigned)(unsigned long)(lds_void*)dys);
     }
   };
   // The two passes of a layer -- the partner's column tiles, shipped at once, then the own ones, to which the partner's
@@ -1740,10 +1747,13 @@ __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd4_kernel(CoopBwd2Args a) 
     if constexpr (HEAD) {
       typedef __attribute__((address_space(3))) void lds_void;
       const int tcl = tau > 0 ? tau : 0;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.dyt) + (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16;
+      // (per-lane clamp to the last 16 bytes of dyt: see the CU-pair kernel)
+      const size_t off = (((size_t)tcl * N + row0) * 16) * sizeof(T) + lane * 16;
+      const size_t last = (size_t)a.Tn * N * 16 * sizeof(T) - 16;
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(a.dyt);
       const unsigned lb = (unsigned)(unsigned long)(lds_void*)dys;
-      c4_lds_dma16(src, lb);
-      c4_lds_dma16(src + 1024, lb + 1024);
+      c4_lds_dma16(base + (off < last ? off : last), lb);
+      c4_lds_dma16(base + (off + 1024 < last ? off + 1024 : last), lb + 1024);
     }
   };
 
@@ -2057,13 +2067,15 @@ int nppc_lstm2_coop_plan(int prec, int train, long N, int H, int n_cu, int* G, i
 static int fwd_coop_impl(int prec, int train, int G, int mtile, const void* x, const void* wp1, const void* wp2,
                          const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
                          void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
-                         float* hpart, int O, void* stream) {
+                         float* hpart, int O, void* stream, int x_ld = 0) {
   if (prec != NPPC_PREC_BF16 || H != 384 || (G != 2 && G != 4 && G != 8)) return NPPC_EUNSUPPORTED;
   if (!x || !wp1 || !wp2 || (!h2 && (!whp || train)) || !xch || !flags || N <= 0 || Tn <= 0 || I > 64) return NPPC_EBADARG;
   if (train && (!h1 || !g1 || !g2 || !c1 || !c2)) return NPPC_EBADARG;
   if (whp && (G != 2 || !hpart || O < 1 || O > 16)) return NPPC_EBADARG;
   const int MC = 16 * mtile;
-  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC), whp, hpart, O};
+  if (x_ld == 0) x_ld = 64;
+  if (x_ld % 8 || x_ld > 64 || x_ld <= I) return NPPC_EBADARG;
+  CoopArgs a{x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, flags, N, Tn, (int)((N + MC - 1) / MC), whp, hpart, O, x_ld};
   hipStream_t s = (hipStream_t)stream;
   if (G == 8) {
     // eight CUs per cluster (48 hidden units = 3 waves each, 1/8 of the weight stream per CU): for the few long sequences
@@ -2105,10 +2117,10 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
 int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2,
                              const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
                              void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
-                             float* hpart, int O, void* stream) {
+                             float* hpart, int O, int x_ld, void* stream) {
   if (!whp) return NPPC_EBADARG;
   return fwd_coop_impl(prec, train, 2, mtile, x, wp1, wp2, bias1, bias2, h2, h1, g1, g2, c1, c2, xch, xch_bytes, flags, N, Tn, I,
-                       H, whp, hpart, O, stream);
+                       H, whp, hpart, O, stream, x_ld);
 }
 
 // cooperative backward (bf16, H = 384, I <= 64): packed weights of nppc_lstm2_coop_bwd_pack; xch holds

@@ -309,6 +309,9 @@ struct MidBwdArgs {
   // optional: tile column sums of the block's upstream gradient (nppc_gemm_nt_colsum: [z][cp_tiles][cp_ld]) -> the sconv bias
   // gradient dbias2[z*sP + c], c < cp_cols, added up by the finishing launch
   const float* colpart; int cp_tiles, cp_ld, cp_cols; float* dbias2;
+  // finishing launch over several TCN blocks at once (blockIdx.z = block): element strides between consecutive blocks of the
+  // partial rows, the tile column sums and the parameter gradients (0 for the one-block launch)
+  long partL, colpartL, sL;
 };
 __host__ __device__ __forceinline__ size_t mb_part_stride(int Cc) { return (size_t)MB_PART_ROWS * Cc + 2 * (Cc / MB_CG) + 6; }
 
@@ -528,6 +531,13 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
 __global__ __launch_bounds__(1024) void mid_bwd_finish_kernel(MidBwdArgs g, int B, int nb_main) {
   __shared__ float red[16][64];
   const int z = blockIdx.y, Cc = g.Cc;
+  {
+    const long blk = blockIdx.z;
+    g.part += blk * g.partL;
+    if (g.colpart) { g.colpart += blk * g.colpartL; g.dbias2 += blk * g.sL; }
+    g.dgamma2 += blk * g.sL; g.dbeta2 += blk * g.sL; g.dgamma1 += blk * g.sL; g.dbeta1 += blk * g.sL; g.dbias1 += blk * g.sL;
+    g.dbd += blk * g.sL; g.dwd += blk * g.sL; g.dslope1 += blk * g.sL; g.dslope2 += blk * g.sL;
+  }
   const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
   if ((int)blockIdx.x >= nb_main) {                   // workgroups behind the main ones: the sconv bias gradient from tile sums
     const int c = ((int)blockIdx.x - nb_main) * 64 + col;
@@ -642,7 +652,8 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
                      const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
                      float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1,
                      const float* colpart, int cp_tiles, int cp_ld, int cp_cols, float* dbias2, int B,
-                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream) {
+                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, int finish_now,
+                     void* stream) {
   if (!dA || !y2 || !y1 || !st1 || !st2 || !S || !part || !gamma1 || !beta1 || !gamma2 || !beta2 || !wd || !slope1 || !slope2 || !dpre1 ||
       !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || dil < 1)
     return NPPC_EBADARG;
@@ -651,7 +662,7 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
   hipStream_t s = (hipStream_t)stream;
   MidBwdArgs g{dA, y2, y1, st1, st2, S, gamma1, beta1, gamma2, beta2, wd, slope1, slope2, a2, dpre1, dgamma2, dbeta2,
                dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part,
-               colpart, cp_tiles, cp_ld, cp_cols, dbias2};
+               colpart, cp_tiles, cp_ld, cp_cols, dbias2, 0, 0, 0};
   dim3 grid(Cc / MB_CG, B, batch);
   if (prec == NPPC_PREC_BF16) {
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, g);
@@ -660,9 +671,37 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, g);
     hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), 0, s, g);
   }
+  if (finish_now) {
+    const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2, 64);
+    hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(nb_main + (colpart ? (int)ceil_div(cp_cols, 64) : 0), batch), dim3(1024), 0, s, g,
+                       B, nb_main);
+  }
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+/* the finishing launch of nppc_tcn_mid_bwd(..., finish_now = 0) for `nblk` TCN blocks at once: block k's partial rows at
+ * part + k * partL (each nppc_tcn_mid_bwd_part_elems floats), its tile column sums at colpart + k * colpartL (nullable), its
+ * parameter gradients k * sL elements behind the pointers given (the blocks of a TCN stack sit at a constant stride in the
+ * flat parameter buffer).  Fixed summation order, no atomics; gradients are ACCUMULATED. */
+int nppc_tcn_mid_bwd_finish(const float* part, long partL, const float* colpart, long colpartL, int cp_tiles, int cp_ld,
+                            int cp_cols, float* dgamma2, float* dbeta2, float* dgamma1, float* dbeta1, float* dwd, float* dbd,
+                            float* dslope1, float* dslope2, float* dbias1, float* dbias2, int B, int Cc, long sP, long sL,
+                            int batch, int nblk, void* stream) {
+  if (!part || !dgamma2 || !dbeta2 || !dgamma1 || !dbeta1 || !dwd || !dbd || !dslope1 || !dslope2 || !dbias1 || B <= 0 ||
+      batch <= 0 || nblk <= 0)
+    return NPPC_EBADARG;
+  if (colpart && (!dbias2 || cp_tiles < 1 || cp_cols < 1 || cp_ld < cp_cols)) return NPPC_EBADARG;
+  if (Cc % MB_CG) return NPPC_EUNSUPPORTED;
+  MidBwdArgs g{};
+  g.part = const_cast<float*>(part);
+  g.colpart = colpart; g.cp_tiles = cp_tiles; g.cp_ld = cp_ld; g.cp_cols = cp_cols; g.dbias2 = dbias2;
+  g.dgamma2 = dgamma2; g.dbeta2 = dbeta2; g.dgamma1 = dgamma1; g.dbeta1 = dbeta1; g.dwd = dwd; g.dbd = dbd;
+  g.dslope1 = dslope1; g.dslope2 = dslope2; g.dbias1 = dbias1;
+  g.Cc = Cc; g.sP = sP; g.partL = partL; g.colpartL = colpartL; g.sL = sL;
   const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2, 64);
-  hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(nb_main + (colpart ? (int)ceil_div(cp_cols, 64) : 0), batch), dim3(1024), 0, s, g,
-                     B, nb_main);
+  hipLaunchKernelGGL(mid_bwd_finish_kernel, dim3(nb_main + (colpart ? (int)ceil_div(cp_cols, 64) : 0), batch, nblk), dim3(1024), 0,
+                     (hipStream_t)stream, g, B, nb_main);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

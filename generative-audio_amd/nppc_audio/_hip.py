@@ -90,7 +90,7 @@ SIGS = {
     "nppc_lstm2_fwd": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "nppc_lstm2_coop_plan": [I, I, L, I, I, PI, PI, PI],
     "nppc_lstm2_fwd_coop": [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P],
-    "nppc_lstm2_fwd_coop_head": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P, P, I, P],
+    "nppc_lstm2_fwd_coop_head": [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, L, P, L, I, I, I, P, P, I, I, P],
     "nppc_sb_head_finalize": [P, I, P, P, L, I, I, I, I, P],
     "nppc_lstm2_ws_plan": [I, L, I, I, I, PI, PI],
     "nppc_lstm2_ws_packed_elems": [PL, PL],
@@ -126,7 +126,8 @@ SIGS = {
     "nppc_gemm_nt": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "nppc_tcn_mid_bwd_part_elems": [I, I, I, I, PL],
     "nppc_tcn_mid_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P,
-                         I, I, I, I, I, F, L, L, L, I, P],
+                         I, I, I, I, I, F, L, L, L, I, I, P],
+    "nppc_tcn_mid_bwd_finish": [P, L, P, L, I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, P],
     "nppc_gemm_nt_colsum": [I, I, P, L, L, P, L, L, P, L, L, P, L, P, L, L, I, I, I, I, I, I, I, P, P],
     "nppc_gemm_nt_gn": [I, P, L, L, P, L, L, P, L, L, P, P, L, P, L, L, P, L, D, F, I, I, I, I, I, I, I, P],
     "nppc_tcn_pack_sconv": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, P],

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _hip as H
-from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, bwd_head_fusable, lstm2_backward, lstm2_forward,
+from .ops_lstm import (PackedLSTM, PackedLSTMBwd, ROW_PAD, WGRAD_SPLITS, bwd_head_fusable, forward_x_ld, lstm2_backward, lstm2_forward,
                        own_workspaces, padded_rows,
                        rows_view, workspace)
 
@@ -29,6 +29,8 @@ def rup(a, b):
 TCN_WGRAD_ON_SIDE = os.environ.get("NPPC_TCN_WGRAD_SIDE", "1") != "0"    # A/B switch (tools/diag)
 TCN_WGRAD_SPLITS = int(os.environ.get("NPPC_TCN_S2", "8"))            # K-slices of the TCN weight-gradient GEMMs
 FC_WGRAD_AT_END = os.environ.get("NPPC_FC_AT_END", "1") != "0"       # fc_output_layer weight gradient at the end of the main chain (A/B switch)
+TCN_WGRAD_MAIN_BLOCKS = int(os.environ.get("NPPC_TCN_WGRAD_MAIN_BLOCKS", "1"))   # TCN blocks (0 .. n-1) whose weight gradients stay on the main queue
+MID_FINISH_DEFER = os.environ.get("NPPC_MID_FINISH_DEFER", "1") != "0"   # ONE finishing launch for the eight fused middle backwards (A/B switch)
 COLSUM_IN_GEMM = os.environ.get("NPPC_COLSUM_IN_GEMM", "1") != "0"   # sconv bias gradients from the producing GEMM's epilogue (A/B switch)
 TN_PAIRED = os.environ.get("NPPC_TN_PAIRED", "1") != "0"              # one pass over the gate gradients per LSTM layer (A/B switch)
 FUSED_HEAD = int(os.environ.get("NPPC_FUSED_HEAD", "3"))    # 0: head kernels; 1: fused in the inference forward; 2: + training forward; 3: + backward
@@ -210,7 +212,9 @@ class FSNEngine:
         if self.packed_version is None:            # first pack: check the constant-stride assumption once
             for i in range(8):
                 for z, br in enumerate(BRANCHES):
-                    for leaf in ("conv1x1.weight", "sconv.weight"):
+                    for leaf in ("conv1x1.weight", "sconv.weight", "conv1x1.bias", "sconv.bias", "norm1.weight", "norm1.bias",
+                                 "norm2.weight", "norm2.bias", "depthwise_conv.weight", "depthwise_conv.bias", "prelu1.weight",
+                                 "prelu2.weight"):
                         assert (self.fp.off[f"fb_model{br}.sequence_model.{i}.{leaf}"][0]
                                 == self.fp.off[f"fb_model.sequence_model.0.{leaf}"][0] + i * lay + z * brs)
         w1, w2 = self.p("fb_model.sequence_model.0.conv1x1.weight"), self.p("fb_model.sequence_model.0.sconv.weight")
@@ -343,11 +347,17 @@ class FSNEngine:
             src, ldS = d["rawmag"], ldF           # RAW padded magnitude (networks.py:133)
         H.call("nppc_subband_mean", prec, src, ldS, d["fb"], ldF, R * ldF, self.mult, d["sbscale"], d["sbwork"], B, F, Tp,
                Tv, self.I, s)
-        H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], d["x_tm"], B, F, Tp, Tv,
-               self.nb, self.G, self.KX, int(train), s)
-        # 7: two-layer LSTM over T' steps for the B*F' sequences
         # mtile None: cooperative kernel when the shape allows; it also takes the output head to fuse (bf16 pair kernel)
         head = (self.Whp, self.O) if (FUSED_HEAD > int(train) and prec == H.PREC_BF16 and self.Opad == 16) else None
+        # the frozen net's fused-head inference launch reads rows of 40 columns (the same buffer, viewed narrower): the
+        # staging kernel writes 37 % less, the recurrent kernel fetches 80 instead of 128 bytes per sequence and step
+        x_tm = d["x_tm"]
+        xld = forward_x_ld(d["Nseq"], self.lstm, train, head) if mtile is None else self.KX
+        if xld != self.KX:
+            x_tm = d["x_rows"].view(-1)[:Tv * d["Nseq"] * xld].view(Tv, d["Nseq"], xld)
+        H.call("nppc_subband_stage", prec, src, ldS, d["fb"], ldF, R * ldF, d["sbscale"], x_tm, B, F, Tp, Tv,
+               self.nb, self.G, xld, int(train), s)
+        # 7: two-layer LSTM over T' steps for the B*F' sequences
         if self.pre_lstm_hook is not None:
             # everything another stream still has in flight must be joined BEFORE a cooperative (CU-pair) kernel goes out:
             # its workgroups need the whole chip to themselves.  The trainer parks the previous step's deferred tail
@@ -355,7 +365,7 @@ class FSNEngine:
             hook, self.pre_lstm_hook = self.pre_lstm_hook, None
             hook()
         FSNEngine.join_all()                  # (a no-op after the trainer's hook; any other caller gets the join for free)
-        lo = lstm2_forward(d["x_tm"], self.lstm, train, mtile, head=head)
+        lo = lstm2_forward(x_tm, self.lstm, train, mtile, head=head)
         d["lstm"] = lo
         # 8: Linear(H -> O) + re-layout + look-ahead crop
         out = torch.empty(B, self.O, d["Fo"], T, dtype=torch.float32, device=self.dev)
@@ -634,7 +644,8 @@ class FSNEngine:
         # bias gradient is their sum over the tiles, added up by the block's fused middle backward -- no pass over dXo for it
         bk = 64 if prec == H.PREC_BF16 else 32
         cs_ok = tn_ok and COLSUM_IN_GEMM and ldF % bk == 0 and TCN_HIDDEN % bk == 0
-        cpL = [ws(f"colpart_{i}", (3, R // 128, ldC), torch.float32) for i in range(8)] if cs_ok else None
+        cp_all = ws("colpart", (8, 3, R // 128, ldC), torch.float32) if cs_ok else None      # one block per TCN block
+        cpL = [cp_all[i] for i in range(8)] if cs_ok else None
         if cs_ok:
             H.call("nppc_gemm_nt_colsum", prec, EPI_MASK_POS, dpre_fb, ldF, R * ldF, self.WfcT, ldF, ldC * ldF, dXa, ldC, R * ldC,
                    None, 0, X8, ldC, R * ldC, R, ldC, ldF, Tp, Tv, C, 3, cpL[7], s)
@@ -646,7 +657,24 @@ class FSNEngine:
         h1b = ws("h1b", (3, B, Tp, TCN_HIDDEN))
         h2b = ws("h2b", (3, B, Tp, TCN_HIDDEN))
         Smid = ws("Smid", (3, B, TCN_HIDDEN // 64, 8), torch.float64)      # channel-group shares of the per-sample sums
-        Pmid = ws("Pmid", (H.mid_bwd_part_elems(B, TCN_HIDDEN, Tp, 3),), torch.float32)
+        # partial rows of the fused middle backward, one set per TCN block: their finishing pass (sum over the samples into the
+        # parameter gradients) runs as ONE launch for all eight blocks behind the loop -- or as two (blocks 7..4, then 3..0) when the
+        # data-parallel exchange sends blocks 7..4 early.  Eight 5-us launches each waited up to 0.5 ms for CUs beside the
+        # weight-gradient GEMMs of the side queue (profiles/r03_bench_c2_bf16_windows.txt)
+        n_part = H.mid_bwd_part_elems(B, TCN_HIDDEN, Tp, 3)
+        Pmid = ws("Pmid", (8, n_part), torch.float32)
+        lay = self.fp.off["fb_model.sequence_model.1.conv1x1.weight"][0] - self.fp.off["fb_model.sequence_model.0.conv1x1.weight"][0]
+
+        def finish_mid(lo, hi):
+            """finishing pass of blocks lo .. hi-1"""
+            pre_ = f"fb_model.sequence_model.{lo}."
+            H.call("nppc_tcn_mid_bwd_finish", Pmid[lo], n_part, cpL[lo] if cs_ok else None, 3 * (R // 128) * ldC, R // 128, ldC, C,
+                   self.g(pre_ + "norm2.weight"), self.g(pre_ + "norm2.bias"), self.g(pre_ + "norm1.weight"), self.g(pre_ + "norm1.bias"),
+                   self.g(pre_ + "depthwise_conv.weight"), self.g(pre_ + "depthwise_conv.bias"), self.g(pre_ + "prelu1.weight"),
+                   self.g(pre_ + "prelu2.weight"), self.g(pre_ + "conv1x1.bias"), self.g(pre_ + "sconv.bias") if cs_ok else None,
+                   B, TCN_HIDDEN, sP, lay, 3, hi - lo, s)
+        early = self.grad_range_hook is not None and self.early_buckets_ok
+        defer_finish = MID_FINISH_DEFER        # (A/B switch NPPC_MID_FINISH_DEFER=0: one finishing launch per block, as in round 3)
         dXo, dXi = dXa, dXb
         for i in range(7, -1, -1):
             pre = f"fb_model.sequence_model.{i}."
@@ -666,24 +694,35 @@ class FSNEngine:
             # GroupNorm-2, PReLU-2, depthwise conv, GroupNorm-1, PReLU-1 backward in one reduce + one apply pass: h1b -> h2b
             # (= gradient of the conv1x1 output) with every parameter gradient of those stages and the conv1x1 bias gradient;
             # the reduce pass also leaves a2 = GN2(y2), the operand of the sconv weight gradient
-            H.call("nppc_tcn_mid_bwd", prec, h1b, y2, y1, st1, st2, Smid, Pmid, self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
+            H.call("nppc_tcn_mid_bwd", prec, h1b, y2, y1, st1, st2, Smid, Pmid[i], self.p(pre + "norm1.weight"), self.p(pre + "norm1.bias"),
                    self.p(pre + "norm2.weight"), self.p(pre + "norm2.bias"), self.p(pre + "depthwise_conv.weight"),
                    self.p(pre + "prelu1.weight"), self.p(pre + "prelu2.weight"), a2, h2b, self.g(pre + "norm2.weight"),
                    self.g(pre + "norm2.bias"), self.g(pre + "norm1.weight"), self.g(pre + "norm1.bias"),
                    self.g(pre + "depthwise_conv.weight"), self.g(pre + "depthwise_conv.bias"), self.g(pre + "prelu1.weight"),
                    self.g(pre + "prelu2.weight"), self.g(pre + "conv1x1.bias"),
                    cpL[i] if cs_ok else None, R // 128, ldC, C, self.g(pre + "sconv.bias") if cs_ok else None,
-                   B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, s)
+                   B, TCN_HIDDEN, Tp, Tv, dil, 1e-8, sAct, B * 2, sP, 3, 0 if defer_finish else 1, s)
+            if i == 4 and early and defer_finish:
+                finish_mid(4, 8)              # blocks 7..4 are handed to the exchange below: their gradients must be final
             # sconv weight gradient: dW2[c][k] = sum_r dXo[r][c] * a2[r][k]
             if tn_ok:
                 # row-major operands as they are: slab[k][c] = sum_r a2[r][k] * dXo[r][c] = dW2^T, transposed in the reduction
-                def sconv_wgrad(a2=a2, dXo=dXo, dest=self.g(pre + "sconv.weight")):
+                # (blocks i < TCN_WGRAD_MAIN_BLOCKS -- the last ones of the chain -- keep their two products on the MAIN queue,
+                # with a slab of their own: since the eight finishing launches became one the side queue is the longer one,
+                # profiles/r04_bench_c2_bf16_windows.txt)
+                inline = i < TCN_WGRAD_MAIN_BLOCKS
+                wslab = ws("slab_main", (3 * S2 * TCN_HIDDEN * ldC,), torch.float32) if inline else slab2
+
+                def sconv_wgrad(a2=a2, dXo=dXo, dest=self.g(pre + "sconv.weight"), wslab=wslab):
                     q = H.stream()
-                    H.call("nppc_gemm_tn_splitk_batched", a2, TCN_HIDDEN, sAct, dXo, ldC, R * ldC, slab2, ldC,
+                    H.call("nppc_gemm_tn_splitk_batched", a2, TCN_HIDDEN, sAct, dXo, ldC, R * ldC, wslab, ldC,
                            S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, q)
-                    H.call("nppc_reduce_slabs_t", slab2, S2, TCN_HIDDEN * ldC, ldC, dest, TCN_HIDDEN, C, TCN_HIDDEN,
+                    H.call("nppc_reduce_slabs_t", wslab, S2, TCN_HIDDEN * ldC, ldC, dest, TCN_HIDDEN, C, TCN_HIDDEN,
                            S2 * TCN_HIDDEN * ldC, sP, 3, q)
-                on_side(sconv_wgrad)
+                if inline:
+                    sconv_wgrad()
+                else:
+                    on_side(sconv_wgrad)
             else:
                 H.call("nppc_transpose", prec, dXo, tA, R, ldC, ldC, R, R * ldC, sTA, 0, 3, s)
                 H.call("nppc_transpose", prec, a2, tB, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTB, 0, 3, s)
@@ -692,13 +731,16 @@ class FSNEngine:
             # conv1x1: weight, input gradients (the bias gradient came out of the fused kernel)
             if tn_ok:
                 # slab[k][c] = sum_r dpre1[r][k] * Xin[r][c] = dW1
-                def c1_wgrad(h2b=h2b, Xin=Xin, dest=self.g(pre + "conv1x1.weight")):
+                def c1_wgrad(h2b=h2b, Xin=Xin, dest=self.g(pre + "conv1x1.weight"), wslab=wslab):
                     q = H.stream()
-                    H.call("nppc_gemm_tn_splitk_batched", h2b, TCN_HIDDEN, sAct, Xin, ldC, R * ldC, slab2, ldC,
+                    H.call("nppc_gemm_tn_splitk_batched", h2b, TCN_HIDDEN, sAct, Xin, ldC, R * ldC, wslab, ldC,
                            S2 * TCN_HIDDEN * ldC, TCN_HIDDEN, ldC, R, S2, 3, q)
-                    H.call("nppc_reduce_slabs", slab2, S2, TCN_HIDDEN * ldC, ldC, dest, C, TCN_HIDDEN, 0, C, 0, 0,
+                    H.call("nppc_reduce_slabs", wslab, S2, TCN_HIDDEN * ldC, ldC, dest, C, TCN_HIDDEN, 0, C, 0, 0,
                            S2 * TCN_HIDDEN * ldC, sP, 3, q)
-                on_side(c1_wgrad)
+                if inline:
+                    c1_wgrad()
+                else:
+                    on_side(c1_wgrad)
             else:
                 H.call("nppc_transpose", prec, h2b, tA, R, TCN_HIDDEN, TCN_HIDDEN, R, sAct, sTA, 0, 3, s)
                 H.call("nppc_transpose", prec, Xin, tB, R, ldC, ldC, R, R * ldC, sTB, 0, 3, s)
@@ -719,6 +761,8 @@ class FSNEngine:
                         b, shp = self.fp.off[f"fb_model{br}.sequence_model.7.sconv.bias"]
                         self.grad_range_hook(G, a, b + int(np.prod(shp)))
                 on_side(blocks_done)
+        if defer_finish:
+            finish_mid(0, 4 if early else 8)
         if tn_ok:
             dXo = dXL[0]
         # ---- 7. TSSE attention backward (parameter gradients only: the maps are data)

@@ -191,7 +191,8 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
     and the result carries head_partial [2][Tn][N][O] fp32 (the caller finishes with nppc_sb_head_finalize) -- in
     inference INSTEAD of h2, in training beside the saved state; any other plan ignores `head`."""
     Tn, N, kx = x_tm.shape
-    assert kx == packed.kx and x_tm.dtype == H.dtype_of(packed.prec)
+    # kx < packed.kx: rows staged at a packed width (forward_x_ld) -- only the fused-head CU-pair inference launch takes them
+    assert (kx == packed.kx or (kx == forward_x_ld(N, packed, train, head) and mtile is None)) and x_tm.dtype == H.dtype_of(packed.prec)
     Hd = packed.Hd
     dt, dev = x_tm.dtype, x_tm.device
     tag = ("lstm", id(packed), train)
@@ -237,9 +238,10 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
                 _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
                     "nppc_lstm2_fwd_coop_head", packed.prec, int(train), cmt, x_tm, packed.wp1, packed.wp2, packed.bias1,
                     packed.bias2, out.get("h2"), out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"),
-                    xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, whp, out["head_partial"], O,
+                    xch, xch.numel() * xch.element_size(), flags, N, Tn, packed.I, Hd, whp, out["head_partial"], O, kx,
                     H.stream()))
                 return out
+            assert kx == packed.kx
             if not train:
                 out["h2"] = workspace(tag + ("h2",), (Tn, N, Hd), dt, dev)
             _timed((f"lstm2_fwd_coop_g{G}", int(train), N, Tn, cmt), lambda: H.call(
@@ -256,6 +258,24 @@ def lstm2_forward(x_tm, packed, train, mtile=None, head=None):
         out["h2"], out.get("h1"), out.get("g1"), out.get("g2"), out.get("c1"), out.get("c2"), N, Tn, packed.I, Hd,
         H.stream()))
     return out
+
+
+# packed input rows for the frozen restorer's inference launch (CU-pair kernel with the fused head): 40 columns instead of 64
+# (34 features + the spare column + pad to 16 bytes), -37 % of the staged bytes and of the kernel's x reads.  "0" = 64 columns.
+X_PACKED = os.environ.get("NPPC_X_PACKED", "1") != "0"
+
+
+def forward_x_ld(N, packed, train, head):
+    """row width (elements) the staging kernel should write for lstm2_forward(x, packed, train, None, head): packed.kx unless the
+    launch will be the fused-head CU-pair inference kernel, which fetches rows of any 16-byte multiple width"""
+    if (not X_PACKED or train or head is None or not COOP or packed.prec != H.PREC_BF16 or packed.Hd != 384
+            or head[1] > FUSED_HEAD_MAX_O or packed.I + 1 > 40):
+        return packed.kx
+    if WS and _ws_wanted(N, packed, train) and ws_plan(N, packed) is not None:
+        return packed.kx
+    G, cmt, ncl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    H.call("nppc_lstm2_coop_plan", packed.prec, 0, N, packed.Hd, _n_cu(), ctypes.byref(G), ctypes.byref(cmt), ctypes.byref(ncl))
+    return 40 if (ncl.value > 0 and G.value == 2) else packed.kx
 
 
 def _ws_wanted(N, packed, train):

@@ -139,7 +139,16 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
                      const float* slope1, const float* slope2, void* a2, void* dpre1, float* dgamma2, float* dbeta2,
                      float* dgamma1, float* dbeta1, float* dwd, float* dbd, float* dslope1, float* dslope2, float* dbias1,
                      const float* colpart, int cp_tiles, int cp_ld, int cp_cols, float* dbias2, int B,
-                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, void* stream);
+                     int Cc, int Tp, int Tv, int dil, float eps, long sAct, long sSt, long sP, int batch, int finish_now,
+                     void* stream);
+/* finish_now = 0 defers the finishing launch: one nppc_tcn_mid_bwd_finish then adds up the partial rows of `nblk` blocks at
+ * once (block k: part + k * partL, colpart + k * colpartL, gradients k * sL elements behind the pointers given -- the blocks of
+ * the TCN stack sit at a constant stride in the flat buffer).  Round 3 ran eight 5-us finishing launches per step, each of
+ * which waited up to 0.5 ms for CUs beside the weight-gradient GEMMs of the side queue. */
+int nppc_tcn_mid_bwd_finish(const float* part, long partL, const float* colpart, long colpartL, int cp_tiles, int cp_ld,
+                            int cp_cols, float* dgamma2, float* dbeta2, float* dgamma1, float* dbeta1, float* dwd, float* dbd,
+                            float* dslope1, float* dslope2, float* dbias1, float* dbias2, int B, int Cc, long sP, long sL,
+                            int batch, int nblk, void* stream);
 /* sconv of a TCNBlock with the GroupNorm in front of it (norm2, causal_conv.py:104-106) folded into the product:
  *   C = rstd_b * (A Wg^T) - mean_b * rstd_b * v + u + res,  A = the un-normalised depthwise output, stats = its per-sample
  * (sum, sumsq), cnt = elements per sample; nppc_tcn_pack_sconv builds Wg[n][k] = gamma[k] W[n][k], v[n] = sum_k Wg[n][k],
@@ -215,7 +224,9 @@ int nppc_lstm2_fwd_coop(int prec, int train, int G, int mtile, const void* x, co
 int nppc_lstm2_fwd_coop_head(int prec, int train, int mtile, const void* x, const void* wp1, const void* wp2,
                              const float* bias1, const float* bias2, void* h2, void* h1, void* g1, void* g2, void* c1, void* c2,
                              void* xch, long xch_bytes, unsigned* flags, long N, int Tn, int I, int H, const void* whp,
-                             float* hpart, int O, void* stream);
+                             float* hpart, int O, int x_ld /* row stride of x in elements: 0 or 64 = [Tn][N][64]; a packed width
+                             (multiple of 8, I < x_ld <= 64): only x_ld columns per row are fetched (the frozen restorer's input,
+                             staged 40 wide: -37 % of its bytes) */, void* stream);
 int nppc_sb_head_finalize(const float* hpart, int G, const float* bias, float* out, long Nseq, int Tn, int la, int O, int Fo,
                           void* stream);
 /* Weight-STATIONARY forward of the same LSTM (sequence_model.py:113-123; bf16, H = 384, I <= 64; any N, the last 32-sequence chunk may be ragged): clusters of

@@ -81,7 +81,7 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv, C):
     H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], a2_out, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
            grads["a1"], grads["a2"], grads["bias1"], colpart, n_tiles, cp_ld, cp_cols, dbias2, B, C, Tp, Tv, dil, EPS, B * Tp * C,
-           B * 2, sP, Z, H.stream())
+           B * 2, sP, Z, 1, H.stream())
     torch.cuda.synchronize()
     tol = 2e-4 if prec == 1 else 4e-2
     for z in range(Z):
@@ -108,13 +108,38 @@ def test_mid_block_backward_matches_autograd(prec, dil, Tv, C):
     first = {k: v.clone() for k, v in grads.items()}
     H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, part, par["g1"], par["b1"], par["g2"], par["b2"], par["wd"],
            par["a1"], par["a2"], None, dpre1, grads["g2"], grads["b2"], grads["g1"], grads["b1"], grads["wd"], grads["bd"],
-           grads["a1"], grads["a2"], grads["bias1"], None, 0, 0, 0, None, B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z,
+           grads["a1"], grads["a2"], grads["bias1"], None, 0, 0, 0, None, B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, 1,
            H.stream())
     torch.cuda.synchronize()
     got2 = torch.stack([grads["g1"][z * sP: z * sP + C] for z in range(Z)])
     assert rel(got2, 2 * Pr["g1"].grad) < tol
     for k in grads:
         assert torch.equal(grads[k], 2 * first[k]), k
+    # deferred finishing pass (finish_now = 0) over TWO "blocks" at once: the partial rows of the call above in two part
+    # buffers, gradients at a block stride sL inside one flat buffer -> both blocks receive exactly the first launch's sums
+    n_part = H.mid_bwd_part_elems(B, C, Tp, Z)
+    parts = torch.full((2, n_part), float("nan"), device="cuda")
+    sL = 600                                                      # block stride (elements) inside the branch stride sP
+    assert 3 * C <= sL and 2 * sL <= sP
+    g2 = {k: torch.zeros(Z * sP, device="cuda") for k in grads}
+    colparts = colpart.unsqueeze(0).repeat(2, 1, 1, 1).contiguous()
+    dbias2b = torch.full((Z * sP,), float("nan"), device="cuda")
+    for blk in range(2):
+        H.call("nppc_tcn_mid_bwd", prec, dA_tm, y2_tm, y1_tm, st1, st2, S, parts[blk], par["g1"], par["b1"], par["g2"], par["b2"],
+               par["wd"], par["a1"], par["a2"], None, dpre1, g2["g2"], g2["b2"], g2["g1"], g2["b1"], g2["wd"], g2["bd"],
+               g2["a1"], g2["a2"], g2["bias1"], None, 0, 0, 0, None, B, C, Tp, Tv, dil, EPS, B * Tp * C, B * 2, sP, Z, 0, H.stream())
+    torch.cuda.synchronize()
+    assert all(float(v.abs().max()) == 0.0 for v in g2.values())          # nothing is added before the finishing launch
+    H.call("nppc_tcn_mid_bwd_finish", parts, n_part, colparts, Z * n_tiles * cp_ld, n_tiles, cp_ld, cp_cols, g2["g2"], g2["b2"],
+           g2["g1"], g2["b1"], g2["wd"], g2["bd"], g2["a1"], g2["a2"], g2["bias1"], dbias2b, B, C, sP, sL, Z, 2, H.stream())
+    torch.cuda.synchronize()
+    for k, n in (("g2", C), ("b2", C), ("g1", C), ("b1", C), ("wd", 3 * C), ("bd", C), ("a1", 1), ("a2", 1), ("bias1", C)):
+        for z in range(Z):
+            for blk in range(2):
+                assert torch.equal(g2[k][z * sP + blk * sL: z * sP + blk * sL + n], first[k][z * sP: z * sP + n]), (k, z, blk)
+    for z in range(Z):
+        for blk in range(2):
+            assert torch.equal(dbias2b[z * sP + blk * sL: z * sP + blk * sL + cp_cols], dbias2[z * sP: z * sP + cp_cols])
 
 
 @pytest.mark.parametrize("prec,C,Tv", [(1, 257, 70), (0, 514, 130)])

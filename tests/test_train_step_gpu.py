@@ -155,6 +155,17 @@ def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
         # real/imag branches (noise-limited even in the reference's fp32) through direction and norm of the whole gradient
         well = [n for n in names if not ill_conditioned(n)]
         assert len(well) > 100
+        # PReLU slopes, one by one: each is a single scalar (a sum over every element of a [B, 512, T'] tensor), so "error / max
+        # |grad| of the tensor" divides by the scalar itself and a slope whose gradient nearly cancels shows a large ratio at a
+        # tiny absolute error (g2_k5: -1.2e-7 next to slopes of 1.2e-6; the ratio of THAT scalar read 0.39, 0.50 and 0.66 in
+        # three bf16 builds whose other families agree to +-50 %).  A scalar is therefore measured against max(|itself|, a
+        # quarter of the largest slope gradient of its kind); the 8 slopes of a kind as ONE vector are held below as well.
+        for kind in ("prelu1", "prelu2"):
+            sl = [n for n in well if n.endswith(kind + ".weight")]
+            scale = max(abs(float(ref[n].reshape(-1)[0])) for n in sl)
+            for n in sl:
+                r0 = float(ref[n].reshape(-1)[0])
+                worst[n] = abs(float(got[n].grad.double().cpu().reshape(-1)[0]) - r0) / max(abs(r0), 0.25 * scale)
         fam = {}
         for n in well:
             k = ("sb_model" if ".sb_model." in n else "attention" if "channel_attention" in n else
@@ -164,10 +175,8 @@ def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
         for k, v in fam.items():
             record_err("bf16_grad." + k, v, bf16_grad_tol("x" + (".prelu" if "prelu" in k else "")))
         record_err("bf16_grad.cos_deficit", 1.0 - cos, 0.01)
-        # The PReLU slopes are single scalars (sums over every element of a [B, 512, T'] tensor): "error / max|grad| of the
-        # tensor" divides by the scalar itself, so a slope whose gradient nearly cancels shows a large ratio at a small
-        # absolute error.  Held as well the way a channel vector is: the 8 slopes of a kind (prelu1 / prelu2 of the 8 TCN
-        # blocks of the branch) as ONE tensor, error / max |grad| over the 8.
+        # ... and the way a channel vector is held: the 8 slopes of a kind (prelu1 / prelu2 of the 8 TCN blocks of the branch)
+        # as ONE tensor, error / max |grad| over the 8.
         for kind in ("prelu1", "prelu2"):
             sl = [n for n in well if n.endswith(kind + ".weight")]
             rv = np.array([float(ref[n].reshape(-1)[0]) for n in sl])

@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     a2, dpre = torch.empty_like(dA), torch.empty_like(dA)
     def run():
         H.call("nppc_tcn_mid_bwd", 0, dA, y2, y1, st, st, S, part, p[0], p[1], p[2], p[3], p[4], p[5], p[6], a2, dpre, *gr, None, 0, 0, 0, None, B, C, Tp, Tv,
-               dil, 1e-8, B * Tp * C, B * 2, sP, Z, H.stream())
+               dil, 1e-8, B * Tp * C, B * 2, sP, Z, 1, H.stream())
     for _ in range(5):
         run()
     torch.cuda.synchronize()
