@@ -42,8 +42,9 @@ NFFT, HOP, NF = 512, 256, 257
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3       # fp32 matrix (= vector) peak
 PEAK_HBM_GBS = 8000.0
-PMC_CSV = os.path.join(ROOT, "profiles", "r03_bench_c2_bf16_pmc_traffic.csv")
-PMC_STAMP = os.path.join(ROOT, "profiles", "r03_bench_c2_bf16_pmc_stamp.json")
+PMC_CSV = os.path.join(ROOT, "profiles", "r04_bench_c2_bf16_pmc_traffic.csv")
+PMC_STAMP = os.path.join(ROOT, "profiles", "r04_bench_c2_bf16_pmc_stamp.json")
+PMC_C5 = (os.path.join(ROOT, "profiles", "r04_bench_c5_bf16_pmc_traffic.csv"), os.path.join(ROOT, "profiles", "r04_bench_c5_bf16_pmc_stamp.json"))
 
 
 def build_trainer(precision, rank, world, batch, length, n_dirs=K_DIRS):
@@ -226,6 +227,9 @@ ROCPROF_NAME = {   # bench label prefix -> substring of the rocprofv3 kernel nam
     "lstm2_bwd_coop_ksplit": "lstm2_coop_bwd2_kernel",
     "lstm2_fwd_coop_g2[N=8224": "2, 5, 64, false",
     "lstm2_fwd_coop_g2_train[N=4096": "2, 2, 64, true",
+    "lstm2_fwd_coop_g4_train": "4, 2, 64, true",
+    "lstm2_fwd_ws_train": "lstm2_ws_fwd_kernel<true>",
+    "lstm2_fwd_ws": "lstm2_ws_fwd_kernel<false>",
 }
 
 
@@ -417,7 +421,10 @@ def main():
         d = kern[dom_name]
         roof.update(achieved=d["tflops"], frac=d["tflops"] / peak, avg_ms=d["ms"])
         pat = next((v for k, v in ROCPROF_NAME.items() if dom_name.startswith(k)), None)
-        roof["traffic"], roof["traffic_note"] = pmc_traffic(pat, workload)
+        if workload == "C5":      # BASELINE config 5 has counter passes of its own
+            roof["traffic"], roof["traffic_note"] = pmc_traffic(pat, workload, PMC_C5[0], PMC_C5[1], expect="C5")
+        else:
+            roof["traffic"], roof["traffic_note"] = pmc_traffic(pat, workload)
     else:
         roof.update(achieved=None, frac=None, avg_ms=rank_ms.get(dom_name))
     if fam is not None:

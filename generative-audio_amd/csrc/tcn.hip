@@ -193,7 +193,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
   const T* ga = reinterpret_cast<const T*>(g.A) + (size_t)z * g.strideA + (size_t)ksl * g.K + (long)(m0 + srow) * g.lda + sc * EPC;
   const T* gb = reinterpret_cast<const T*>(g.B) + (size_t)z * g.strideB + (size_t)ksl * g.K + (long)(n0 + srow) * g.ldb + sc * EPC;
   const int soff = srow * 128 + ((sc ^ (srow & 7)) << 4);
+  // diagnostic builds (tools/diag/nt_variants.py; timing only): NT_DIAG_NOLOOP = one K stage instead of K / BK (what the launch,
+  // the first stage's latency and the epilogue cost without the main loop), NT_DIAG_NOEPI = no epilogue (one store per lane).
+  // Measured at the TCN shapes (profiles/r04_nt_variants.txt): 38 us = 12 us launch + first stage, 14 us for the other eight
+  // stages (one stage of prefetch: a stage takes the memory latency, 4-6 us would be MFMA-bound), 12-15 us epilogue.  Two
+  // register stages of prefetch were tried again in round 4 (named registers, unconditional clamped loads): hipcc still
+  // drains the queue (vmcnt(0)) in front of the LDS stores and spills at 256 VGPRs -- a deeper pipeline here needs the
+  // inline-asm LDS-DMA ring of gemm_tn_dma_kernel, not built.
+#ifdef NT_DIAG_NOLOOP
+  const int nstage = 1;
+#else
   const int nstage = g.K / BK;
+#endif
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define NGLOAD(k0)                                                            \
   {                                                                           \
@@ -265,6 +276,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
   }
 #undef NGLOAD
 #undef NLSTORE
+#ifdef NT_DIAG_NOEPI
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) v += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    reinterpret_cast<T*>(g.C)[(size_t)blockIdx.z * g.strideC + (size_t)(m0 + (tid >> 1)) * g.ldc + n0 + (tid & 1)] = from_f32<T>(v);
+    return;
+  }
+#endif
   // ---- epilogue (identical to gemm_nt_kernel): element (row m0 + wm*64 + 16 i + 4 q + r, col n0 + wn*BN/2 + 16 j + n)
   T* C = reinterpret_cast<T*>(g.C) + (size_t)blockIdx.z * g.strideC;
   float* Cf = reinterpret_cast<float*>(g.C) + (size_t)blockIdx.z * g.strideC;

@@ -422,11 +422,25 @@ __global__ __launch_bounds__(256) void mid_bwd_reduce_kernel(MidBwdArgs g) {
   mb_channel_sums<2>(ch, sm, part, Cc, c0, ct);
 }
 
+// Apply pass.  Round 4: the gradient of the depthwise OUTPUT, du[t] = PReLU2'(y2[t]) rstd2 (dA[t] gamma2 - S1/n - xh2[t] S2/n), is
+// computed ONCE per element into LDS (phase A) and read back at the three taps (phase B); round 3 recomputed it per tap --
+// two extra loads of (dA, y2) and ~20 of the ~50 vector instructions per element of a pass that is VALU-bound.  The time axis is
+// walked in chunks of `chunk` frames (+ dil frames of halo on either side) so that the staging rows fit two workgroups per CU
+// at any clip length: LDS = (chunk + 2 dil) x (64 + 4) floats + the reduction scratch.  Same arithmetic per element as before.
+constexpr int MB_DU_LD = MB_CG + 4;      // row stride (floats) of the du staging: the 8 frame lanes of a wave hit disjoint banks
+__host__ __device__ __forceinline__ int mb_apply_chunk(int Tv) { const int n = (Tv + 223) / 224; return (Tv + n - 1) / n; }
+__host__ __device__ __forceinline__ size_t mb_apply_smem(int Tv, int dil) {
+  return ((size_t)(mb_apply_chunk(Tv) + 2 * dil) * MB_DU_LD + 4 * 7 * MB_CG + 8) * sizeof(float);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
-  __shared__ float sm[4 * 7 * MB_CG];
-  __shared__ float sl[2][4];
+  extern __shared__ __attribute__((aligned(16))) float mb_dyn[];
   const int z = blockIdx.z, b = blockIdx.y, Cc = g.Cc, Tp = g.Tp, Tv = g.Tv, dil = g.dil;
+  const int chunk = mb_apply_chunk(Tv);
+  float* du_s = mb_dyn;                                        // [(chunk + 2 dil)][MB_DU_LD]
+  float* sm = du_s + (size_t)(chunk + 2 * dil) * MB_DU_LD;     // [4][7][64]
+  float (*sl)[4] = reinterpret_cast<float(*)[4]>(sm + 4 * 7 * MB_CG);
   const int ct = threadIdx.x & 7, fl = threadIdx.x >> 3, c0 = blockIdx.x * MB_CG, c8 = c0 + ct * 8;
   const T* dA = reinterpret_cast<const T*>(g.dA) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
   const T* y2 = reinterpret_cast<const T*>(g.y2) + (size_t)z * g.sAct + (size_t)b * Tp * Cc + c8;
@@ -467,13 +481,37 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
       for (int k = 0; k < 3; ++k) w8[k][i] = w24[i * 3 + k];
     }
   }
-  for (int t = fl; t < Tp; t += MB_FL) {
-    float out[8];
+  for (int f0 = 0; f0 < Tv; f0 += chunk) {
+    const int f1 = f0 + chunk < Tv ? f0 + chunk : Tv;          // the chunk's own frames [f0, f1)
+    const int lo = f0 - dil > 0 ? f0 - dil : 0, hi = f1 + dil < Tv ? f1 + dil : Tv;   // ... and the du rows its taps read
+    __syncthreads();                                           // everyone is done reading the previous chunk's rows
+    // ---- phase A: du of frames [lo, hi) -> LDS; the sums indexed by the depthwise OUTPUT frame for the chunk's own frames
+    for (int u = lo + fl; u < hi; u += MB_FL) {
+      float dv[8], yv[8], du8[8];
+      load8<T>(dA + (size_t)u * Cc, dv);
+      load8<T>(y2 + (size_t)u * Cc, yv);
+      const bool own = u >= f0 && u < f1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = 0.f;
-    const size_t o = (size_t)t * Cc;
-    if (t < Tv) {
-      float yv1[8], dv[3][8], yv2[3][8];
+      for (int i = 0; i < 8; ++i) {
+        const float y = yv[i];
+        const float xh2 = (y - c2.mean) * c2.rstd;
+        const float dy2 = c2.rstd * (dv[i] * g2[i] - s1 - xh2 * s2);
+        const float du = y > 0.f ? dy2 : sl2 * dy2;
+        du8[i] = du;
+        if (own) {
+          ch[3][i] += du;
+          if (!(y > 0.f)) ds2 += dy2 * y * isl2;
+        }
+      }
+      float* dp = du_s + (size_t)(u - lo) * MB_DU_LD + ct * 8;
+      *reinterpret_cast<float4*>(dp) = make_float4(du8[0], du8[1], du8[2], du8[3]);
+      *reinterpret_cast<float4*>(dp + 4) = make_float4(du8[4], du8[5], du8[6], du8[7]);
+    }
+    __syncthreads();
+    // ---- phase B: the chunk's own frames
+    for (int t = f0 + fl; t < f1; t += MB_FL) {
+      float out[8], yv1[8], du3[3][8];
+      const size_t o = (size_t)t * Cc;
       load8<T>(y1 + o, yv1);
       bool ok[3];
 #pragma unroll
@@ -481,8 +519,10 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
         const int tu = t - (k - 1) * dil;           // depthwise output frame whose tap k reads frame t
         ok[k] = tu >= 0 && tu < Tv;
         if (ok[k]) {
-          load8<T>(dA + (size_t)tu * Cc, dv[k]);
-          load8<T>(y2 + (size_t)tu * Cc, yv2[k]);
+          const float* dp = du_s + (size_t)(tu - lo) * MB_DU_LD + ct * 8;
+          const float4 a = *reinterpret_cast<const float4*>(dp), c = *reinterpret_cast<const float4*>(dp + 4);
+          du3[k][0] = a.x; du3[k][1] = a.y; du3[k][2] = a.z; du3[k][3] = a.w;
+          du3[k][4] = c.x; du3[k][5] = c.y; du3[k][6] = c.z; du3[k][7] = c.w;
         }
       }
 #pragma unroll
@@ -493,16 +533,9 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           if (ok[k]) {
-            const float y = yv2[k][i];
-            const float xh2 = (y - c2.mean) * c2.rstd;
-            const float dy2 = c2.rstd * (dv[k][i] * g2[i] - s1 - xh2 * s2);
-            const float du = y > 0.f ? dy2 : sl2 * dy2;
+            const float du = du3[k][i];
             dz += w8[k][i] * du;
             ch[4 + k][i] += du * z1;
-            if (k == 1) {                             // tu == t: the quantities indexed by the depthwise OUTPUT frame
-              ch[3][i] += du;
-              if (!(y > 0.f)) ds2 += dy2 * y * isl2;
-            }
           }
         ch[0][i] += dz * xh1;
         ch[1][i] += dz;
@@ -513,10 +546,17 @@ __global__ __launch_bounds__(256) void mid_bwd_apply_kernel(MidBwdArgs g) {
         out[i] = dp;
         ch[2][i] += to_f32<T>(from_f32<T>(dp));       // the bias gradient of the STORED (rounded) tensor, as a column sum of it was
       }
+      store8<T>(dpre1 + o, out);
     }
-    store8<T>(dpre1 + o, out);
+  }
+  {                                                            // padded frames [Tv, Tp): zero
+    float zero8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zero8[i] = 0.f;
+    for (int t = Tv + fl; t < Tp; t += MB_FL) store8<T>(dpre1 + (size_t)t * Cc, zero8);
   }
   const float w1 = wave_sum(ds1), w2 = wave_sum(ds2);
+  __syncthreads();                                             // (the staging rows are dead: sl / sm follow)
   if ((threadIdx.x & 63) == 0) { sl[0][threadIdx.x >> 6] = w1; sl[1][threadIdx.x >> 6] = w2; }
   float* part = g.part + ((size_t)z * gridDim.y + b) * mb_part_stride(Cc);
   mb_channel_sums<7>(ch, sm, part + 2 * (size_t)Cc, Cc, c0, ct);      // (its barriers also publish sl)
@@ -664,12 +704,28 @@ int nppc_tcn_mid_bwd(int prec, const void* dA, const void* y2, const void* y1, c
                dgamma1, dbeta1, dwd, dbd, dslope1, dslope2, dbias1, Cc, Tp, Tv, dil, eps, sAct, sSt, sP, part,
                colpart, cp_tiles, cp_ld, cp_cols, dbias2, 0, 0, 0};
   dim3 grid(Cc / MB_CG, B, batch);
+  const size_t smem = mb_apply_smem(Tv, dil);
+  if (smem > 80 * 1024) return NPPC_EUNSUPPORTED;          // (dil far beyond the TCN's 1..9: the staging rows would not fit)
   if (prec == NPPC_PREC_BF16) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mid_bwd_apply_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024) != hipSuccess)
+        return NPPC_ELAUNCH;
+      attr = true;
+    }
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, g);
-    hipLaunchKernelGGL(mid_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<bf16_t>, grid, dim3(256), smem, s, g);
   } else {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(mid_bwd_apply_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024) != hipSuccess)
+        return NPPC_ELAUNCH;
+      attr = true;
+    }
     hipLaunchKernelGGL(mid_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, g);
-    hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(mid_bwd_apply_kernel<float>, grid, dim3(256), smem, s, g);
   }
   if (finish_now) {
     const int nb_main = (int)ceil_div((long)MB_PART_ROWS * Cc + 2, 64);

@@ -38,6 +38,9 @@ struct ConvArgs {
   float slope;
   long P;                             // haloed pixel rows B*(H+2)*(W+2)
   int H, W, Cin, Cout, ntap;          // Cin % 32 == 0
+  // optional (conv_tiled_kernel): per-tile column sums of the STORED output, [tile = row / 128][2: sum, sum of squares][ldp]
+  // fp32 -- the batch statistics of the train-mode BatchNorm that follows, without a pass of its own over the tensor
+  float* stat_part; int ldp;
 };
 
 // row offset of tap t: (dy, dx) = (t/3 - 1, t%3 - 1) for a 3x3 kernel, 0 for 1x1 (arithmetic on a uniform value:
@@ -219,6 +222,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
 #undef CGLOAD
 #undef CLSTORE
   T* C = reinterpret_cast<T*>(g.C);
+  float st1[NJ], st2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) st1[j] = st2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -234,9 +240,63 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
           v = v * g.scale[col] + g.shift[col];
           v = v > 0.f ? v : g.slope * v;
         }
-        C[row * g.ldc + col] = from_f32<T>(v);
+        const T o = from_f32<T>(v);
+        C[row * g.ldc + col] = o;
+        const float vo = to_f32<T>(o);                 // statistics of the stored (rounded) activations, as bn_stats_kernel read them
+        st1[j] += vo;
+        st2[j] += vo * vo;
       }
     }
+  if (g.stat_part) {
+    // column sums of this 128-row tile: 16 rows per lane -> the four row groups of a wave (lanes n, n+16, n+32, n+48) -> the
+    // two waves along M through LDS (the operand buffers are free: the main loop ended with a barrier) -> one store per column
+    float* sp = reinterpret_cast<float*>(&lds[0][0]);           // [wm][stat][BN]
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float a = st1[j], b = st2[j];
+      a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+      b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+      if (q == 0) {
+        sp[(wm * 2 + 0) * BN + wn * (BN / 2) + 16 * j + n] = a;
+        sp[(wm * 2 + 1) * BN + wn * (BN / 2) + 16 * j + n] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float* pt = g.stat_part + (size_t)(m0 / 128) * 2 * g.ldp + n0 + tid;
+      pt[0] = sp[(0 * 2 + 0) * BN + tid] + sp[(1 * 2 + 0) * BN + tid];
+      pt[g.ldp] = sp[(0 * 2 + 1) * BN + tid] + sp[(1 * 2 + 1) * BN + tid];
+    }
+  }
+}
+
+// the per-tile column sums of conv_tiled_kernel -> BatchNorm batch statistics st[c] = sum x, st[C + c] = sum x^2 (fp64), in two
+// small launches with a fixed summation order: slices of the tile list (4 row lanes x 64 channels per workgroup), then the slices
+__global__ __launch_bounds__(256) void bn_parts_reduce_kernel(const float* __restrict__ part, long ntiles, int ldp, int C, int NS,
+                                                              double* __restrict__ scratch) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.y * 64 + cl, sl = blockIdx.x;
+  const long per = (ntiles + NS - 1) / NS, t0 = sl * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long t = t0 + rl; t < t1; t += 4) {
+      a += (double)part[(size_t)t * 2 * ldp + c];
+      b += (double)part[((size_t)t * 2 + 1) * ldp + c];
+    }
+  red[0][rl][cl] = a; red[1][rl][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    scratch[((size_t)sl * 2 + 0) * C + c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
+    scratch[((size_t)sl * 2 + 1) * C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+  }
+}
+__global__ void bn_parts_final_kernel(const double* __restrict__ scratch, int NS, int C, double* __restrict__ st) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;       // e = stat * C + c
+  if (e >= 2 * C) return;
+  const int k = e / C, c = e % C;
+  double a = 0.0;
+  for (int sl = 0; sl < NS; ++sl) a += scratch[((size_t)sl * 2 + k) * C + c];
+  st[e] = a;
 }
 
 // weight [Cout][Cin][kh][kw] fp32 -> forward pack  Wf[Np][ntap][Cinp]       (Wf[co][t][ci] = w[co][ci][t])
@@ -1019,8 +1079,9 @@ static inline int grid_for(long total, int cap = 4096) {
 
 extern "C" {
 
-int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
-                  const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream) {
+static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
+                         const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, float* stat_part,
+                         void* stream) {
   if (!A || !Wp || !C || B <= 0 || H <= 0 || W <= 0) return NPPC_EBADARG;
   if (Cin % 32 || Np % 64 || Cout > Np || (ksize != 1 && ksize != 3) || (scale && !shift)) return NPPC_EUNSUPPORTED;
   if ((long)B * (H + 2) * (W + 2) >= (1L << 31)) return NPPC_EUNSUPPORTED;
@@ -1028,8 +1089,10 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
   g.A = A; g.lda = lda; g.Wp = Wp; g.C = C; g.ldc = ldc; g.bias = bias; g.scale = scale; g.shift = shift; g.slope = slope;
   g.P = (long)B * (H + 2) * (W + 2);
   g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ntap = ksize * ksize;
+  g.stat_part = stat_part; g.ldp = Np;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   hipStream_t st = (hipStream_t)stream;
+  if (stat_part && !(Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32))) return NPPC_EUNSUPPORTED;   // tiled kernel only
   if (Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32)) {
     if (Np % 128 == 0) {
       dim3 grid(round_up(ceil_div(g.P, 128), 8), Np / 128);
@@ -1045,6 +1108,34 @@ int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, lo
   }
   dim3 grid(ceil_div(g.P, 128), Np / 64);
   LAUNCH_T(prec, conv_kernel, grid, g);
+  return NPPC_OK;
+}
+
+int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
+                  const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream) {
+  return conv_fwd_impl(prec, A, lda, Wp, C, ldc, bias, scale, shift, slope, B, H, W, Cin, Cout, Np, ksize, nullptr, stream);
+}
+
+/* the same convolution (no folded BatchNorm), which also leaves the per-tile column sums of its stored output in stat_part
+ * ([ceil(P / 128)][2][Np] floats, P = B (H+2) (W+2)): nppc_bn_stats_from_parts turns them into the batch statistics of the
+ * train-mode BatchNorm that follows (tmp_utils.py:8-37) without a pass over the tensor.  Tiled kernel shapes only
+ * (Cin % 64 == 0 in bf16, % 32 in fp32): NPPC_EUNSUPPORTED otherwise. */
+int nppc_conv_fwd_stats(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, int B, int H, int W,
+                        int Cin, int Cout, int Np, int ksize, float* stat_part, void* stream) {
+  if (!stat_part) return NPPC_EBADARG;
+  return conv_fwd_impl(prec, A, lda, Wp, C, ldc, bias, nullptr, nullptr, 0.f, B, H, W, Cin, Cout, Np, ksize, stat_part, stream);
+}
+
+/* st[c] = sum x, st[C + c] = sum x^2 (fp64, plain stores: no initial state) from the per-tile sums of nppc_conv_fwd_stats;
+ * scratch: 2 * C * 128 doubles.  Fixed summation order: repeated runs are bit-identical. */
+int nppc_bn_stats_from_parts(const float* stat_part, int B, int H, int W, int Np, int C, double* st, double* scratch, void* stream) {
+  if (!stat_part || !st || !scratch || C <= 0 || C > Np || B <= 0) return NPPC_EBADARG;
+  const long ntiles = ceil_div((long)B * (H + 2) * (W + 2), 128);
+  const int NS = ntiles < 128 ? (int)ntiles : 128;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_parts_reduce_kernel, dim3(NS, ceil_div(C, 64)), dim3(256), 0, s, stat_part, ntiles, Np, C, NS, scratch);
+  hipLaunchKernelGGL(bn_parts_final_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, s, scratch, NS, C, st);
+  NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
 

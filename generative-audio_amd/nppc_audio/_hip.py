@@ -179,6 +179,8 @@ SIGS = {
     "nppc_unet_stage_map": [I, P, L, P, L, I, I, I, I, P],
     "nppc_conv_pack": [I, P, P, P, I, I, I, I, I, I, I, P],
     "nppc_conv_fwd": [I, P, L, P, P, L, P, P, P, F, I, I, I, I, I, I, I, P],
+    "nppc_conv_fwd_stats": [I, P, L, P, P, L, P, I, I, I, I, I, I, I, P, P],
+    "nppc_bn_stats_from_parts": [P, I, I, I, I, I, P, P, P],
     "nppc_conv_wgrad": [I, P, L, P, L, P, I, I, I, I, I, I, I, P],
     "nppc_conv_thin_part_elems": [PL],
     "nppc_conv3x3_thin_fwd": [I, P, L, P, P, P, P, F, P, L, I, I, I, I, I, P],

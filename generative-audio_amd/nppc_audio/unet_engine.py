@@ -26,6 +26,7 @@ OUT_LD = 64         # so is the K-channel output of the 1x1 convolution
 DROP_BLOCKS = ("down3", "down4", "up1", "up2")    # double_convs that end in nn.Dropout (unet.py:254-257)
 
 
+BN_STATS_IN_CONV = os.environ.get("NPPC_BN_STATS_IN_CONV", "1") != "0"   # train-mode BatchNorm statistics from the convolution's epilogue (A/B switch)
 THIN = os.environ.get("NPPC_UNET_THIN", "1") != "0"      # direct kernels for the first (1-2 channel) and last (1x1, K <= 8) convolutions
 PROFILE = None      # bench hook: list of (kind, algorithmic flops, start event, end event)
 
@@ -149,6 +150,8 @@ class UNetEngine:
         self.slab = None
         self._thin_part = None
         self.st = torch.zeros(2 * 1024, dtype=torch.float64, device=self.dev)
+        self._statpart = None        # per-tile column sums of a convolution's output (nppc_conv_fwd_stats), sized at first use
+        self._statscr = None
 
     def buf(self, tag, level, ld):
         key = (tag, level, ld)
@@ -161,10 +164,24 @@ class UNetEngine:
         return b
 
     # ------------------------------------------------------------------------------------------ forward
-    def _conv(self, name, cin, cout, ks, x, ldx, y, ldy, level, fold):
+    def _conv(self, name, cin, cout, ks, x, ldx, y, ldy, level, fold, stats=False):
+        """stats=True (train-mode BatchNorm follows): returns the per-tile column sums of the stored output when the tiled kernel
+        runs (they replace the statistics pass over the tensor), else None"""
         B = self.geo[0]
         h, w = self.lv[level]
         cinp, np_ = self._dims(name, cin, cout)
+        if (stats and BN_STATS_IN_CONV and not fold and ks == 3 and not (THIN and cin <= 2 and cout <= 64 and cout % 8 == 0)
+                and cinp % (64 if self.prec == H.PREC_BF16 else 32) == 0):
+            if cinp != ldx:
+                raise RuntimeError(f"{name}: input row width {ldx} != packed K {cinp}")
+            ntiles = (self.P[level] + 127) // 128
+            if self._statpart is None or self._statpart.numel() < ntiles * 2 * np_:
+                self._statpart = torch.empty(max(ntiles * 2 * np_, (self.P[0] + 127) // 128 * 2 * 128), dtype=torch.float32,
+                                             device=self.dev)
+            with _timed("conv_fwd", 2.0 * B * h * w * cin * cout * ks * ks):
+                H.call("nppc_conv_fwd_stats", self.prec, x, ldx, self.wf[name], y, ldy, self.p(name + ".bias"), B, h, w, cinp, cout,
+                       np_, ks, self._statpart, H.stream())
+            return (self._statpart, np_)
         if ks == 3 and cinp != ldx:
             raise RuntimeError(f"{name}: input row width {ldx} != packed K {cinp}")
         ss = self.ss[name] if fold else None
@@ -183,15 +200,21 @@ class UNetEngine:
             H.call("nppc_conv_fwd", self.prec, x, ldx, self.wf[name], y, ldy, self.p(name + ".bias"),
                    ss, ss[cout:] if fold else None, LEAK, B, h, w, cinp, cout, np_, ks, H.stream())
 
-    def _bn_train(self, conv_name, raw, cout, level, y, ldy):
-        """batch statistics -> scale/shift (+ running update) -> LeakyReLU, output possibly a channel slice"""
+    def _bn_train(self, conv_name, raw, cout, level, y, ldy, parts=None):
+        """batch statistics -> scale/shift (+ running update) -> LeakyReLU, output possibly a channel slice.
+        parts: (per-tile column sums left by the convolution's epilogue, their row width) or None (a pass over `raw`)"""
         B = self.geo[0]
         h, w = self.lv[level]
         bn = conv_name[:-1] + str(int(conv_name[-1]) + 1)
         s = H.stream()
         st = self.st[:2 * cout]
-        st.zero_()
-        H.call("nppc_bn_stats", self.prec, raw.t, raw.ld, self.P[level], cout, st, s)
+        if parts is not None:
+            if self._statscr is None:
+                self._statscr = torch.empty(2 * 1024 * 128, dtype=torch.float64, device=self.dev)
+            H.call("nppc_bn_stats_from_parts", parts[0], B, h, w, parts[1], cout, st, self._statscr, s)
+        else:
+            st.zero_()
+            H.call("nppc_bn_stats", self.prec, raw.t, raw.ld, self.P[level], cout, st, s)
         ss = torch.empty(4 * cout, dtype=torch.float32, device=self.dev)
         H.call("nppc_bn_finalize", st, self.p(bn + ".weight"), self.p(bn + ".bias"), self.bnbuf(bn + ".running_mean"),
                self.bnbuf(bn + ".running_var"), ss, cout, float(B * h * w), BN_EPS, BN_MOMENTUM, 1, s)
@@ -209,10 +232,10 @@ class UNetEngine:
             return
         raw_a, act_a, raw_b = self.buf(blk + ".raw_a", level, cout), self.buf(blk + ".act_a", level, cout), self.buf(
             blk + ".raw_b", level, cout)
-        self._conv(na, cin, cout, 3, x, ldx, raw_a.t, cout, level, False)
-        ss_a = self._bn_train(na, raw_a, cout, level, act_a.t, cout)
-        self._conv(nb, cout, cout, 3, act_a.t, cout, raw_b.t, cout, level, False)
-        ss_b = self._bn_train(nb, raw_b, cout, level, out, ldo)
+        pa = self._conv(na, cin, cout, 3, x, ldx, raw_a.t, cout, level, False, stats=True)
+        ss_a = self._bn_train(na, raw_a, cout, level, act_a.t, cout, pa)
+        pb = self._conv(nb, cout, cout, 3, act_a.t, cout, raw_b.t, cout, level, False, stats=True)
+        ss_b = self._bn_train(nb, raw_b, cout, level, out, ldo, pb)
         saved[blk] = dict(x=x, ldx=ldx, raw_a=raw_a, act_a=act_a, raw_b=raw_b, out=out, ldo=ldo, ss_a=ss_a, ss_b=ss_b,
                           cin=cin, cout=cout, level=level, path=path)
 

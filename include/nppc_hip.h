@@ -386,6 +386,15 @@ int nppc_conv_pack(int prec, const float* w, void* wf, void* wb, int Cout, int C
                    int Coutp, void* stream);
 int nppc_conv_fwd(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, const float* scale,
                   const float* shift, float slope, int B, int H, int W, int Cin, int Cout, int Np, int ksize, void* stream);
+/* the same convolution without the folded-BatchNorm epilogue, which also leaves the column sums (sum, sum of squares) of every
+ * 128-row tile of its STORED output in stat_part [ceil(B (H+2) (W+2) / 128)][2][Np] (fp32): the batch statistics of the
+ * train-mode BatchNorm that follows (tmp_utils.py:8-37) come from nppc_bn_stats_from_parts instead of from a pass over the
+ * tensor (nppc_bn_stats).  Tiled-kernel shapes only (Cin % 64 == 0 in bf16, % 32 in fp32; NPPC_EUNSUPPORTED otherwise).
+ * nppc_bn_stats_from_parts: st[c] = sum x, st[C + c] = sum x^2 (fp64, plain stores: no initial state, fixed summation order);
+ * scratch: 2 * C * 128 doubles. */
+int nppc_conv_fwd_stats(int prec, const void* A, long lda, const void* Wp, void* C, long ldc, const float* bias, int B, int H, int W,
+                        int Cin, int Cout, int Np, int ksize, float* stat_part, void* stream);
+int nppc_bn_stats_from_parts(const float* stat_part, int B, int H, int W, int Np, int C, double* st, double* scratch, void* stream);
 int nppc_conv_wgrad(int prec, const void* dY, long lddy, const void* X, long ldx, float* slabs, int M, int N, int B, int H, int W,
                     int ksize, int ksplit, void* stream);
 int nppc_conv_wgrad_transposed(int M, int N);

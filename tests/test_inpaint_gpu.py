@@ -78,6 +78,27 @@ def test_conv_forward_input_gradient_weight_gradient(pname, prec, dtype, tol, B,
     ref = F.conv2d(x, q(w, dtype), b, padding=ks // 2)
     assert rel(Y.get(Cout), ref) < tol
     assert Y.halo_is_zero()
+    if ks == 3:
+        # the same convolution leaving per-tile column sums of its stored output: identical output, and the BatchNorm batch
+        # statistics they add up to equal the statistics pass over the tensor (nppc_bn_stats) to fp32 summation noise
+        Y1 = Halo(B, H, W, Np, dtype)
+        ntiles = (X.P + 127) // 128
+        part = torch.full((ntiles * 2 * Np,), float("nan"), dtype=torch.float32, device="cuda")
+        Hh.call("nppc_conv_fwd_stats", prec, X.t, Cin, wf, Y1.t, Np, b.cuda(), B, H, W, Cin, Cout, Np, ks, part, s)
+        assert torch.equal(Y1.t, Y.t)
+        Cs = Cout // 8 * 8
+        st_ref = torch.zeros(2 * Cs, dtype=torch.float64, device="cuda")
+        Hh.call("nppc_bn_stats", prec, Y.t, Np, X.P, Cs, st_ref, s)
+        st = torch.full((2 * Cs,), float("nan"), dtype=torch.float64, device="cuda")
+        scr = torch.full((2 * Cs * 128,), float("nan"), dtype=torch.float64, device="cuda")
+        Hh.call("nppc_bn_stats_from_parts", part, B, H, W, Np, Cs, st, scr, s)
+        st2 = torch.full_like(st, float("nan"))
+        Hh.call("nppc_bn_stats_from_parts", part, B, H, W, Np, Cs, st2, scr, s)
+        torch.cuda.synchronize()
+        assert torch.equal(st, st2)                                   # fixed summation order
+        n = B * H * W
+        assert float((st[:Cs] - st_ref[:Cs]).abs().max()) < 1e-5 * n ** 0.5 * float(st_ref[Cs:].max() / n) ** 0.5 + 1e-6
+        assert float(((st[Cs:] - st_ref[Cs:]) / st_ref[Cs:]).abs().max()) < 1e-5
     # folded eval-mode BatchNorm + LeakyReLU epilogue
     sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
     Y2 = Halo(B, H, W, Np, dtype)

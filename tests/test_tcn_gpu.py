@@ -37,7 +37,8 @@ def _stats(x_tm, Tv):
     return torch.stack([v.sum(dim=(2, 3)), (v * v).sum(dim=(2, 3))], dim=-1).contiguous()     # [Z,B,2]
 
 
-@pytest.mark.parametrize("prec,dil,Tv,C", [(1, 1, 37, 64), (1, 9, 70, 128), (0, 5, 130, 192), (1, 2, 5, 64)])
+@pytest.mark.parametrize("prec,dil,Tv,C", [(1, 1, 37, 64), (1, 9, 70, 128), (0, 5, 130, 192), (1, 2, 5, 64),
+                                           (1, 9, 250, 64), (0, 2, 241, 128)])      # > 224 frames: two time chunks + halo rows
 def test_mid_block_backward_matches_autograd(prec, dil, Tv, C):
     from nppc_audio import _hip as H
     Z, B, Tp = 3, 2, 256

@@ -24,8 +24,8 @@ NFFT, HOP, K_DIRS = 255, 128, 5
 PEAK = {"bf16": 2500.0, "fp32": 157.3}
 # rocprofv3 kernel name of each HIP-event family (unet_engine.PROFILE kinds) and the committed counter passes of this command
 ROCPROF_NAME = {"conv_fwd": "conv_tiled_kernel", "conv_bwd_data": "conv_tiled_kernel", "conv_wgrad": "gemm_tn_tiled_kernel"}
-PMC_CSV = os.path.join(ROOT, "profiles", "r03_bench_c3_bf16_pmc_traffic.csv")
-PMC_STAMP = os.path.join(ROOT, "profiles", "r03_bench_c3_bf16_pmc_stamp.json")
+PMC_CSV = os.path.join(ROOT, "profiles", "r04_bench_c3_bf16_pmc_traffic.csv")
+PMC_STAMP = os.path.join(ROOT, "profiles", "r04_bench_c3_bf16_pmc_stamp.json")
 
 
 def log(msg):
