@@ -450,12 +450,17 @@ __global__ __launch_bounds__(64) void gs_bwd_solve_t_kernel(const double* __rest
 __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __restrict__ err_norm, float* __restrict__ proj_re,
                                   float* __restrict__ proj_im, float* __restrict__ proj_mag, float* __restrict__ w_norms,
                                   float* __restrict__ reconst, float* __restrict__ sm, double* __restrict__ coefA,
-                                  double* __restrict__ coefE, int B, int K, double eps, int eps_in_norms) {
+                                  double* __restrict__ coefE, int B, int K, double eps, int eps_in_norms, float lam,
+                                  float* __restrict__ objective) {
   // eps_in_norms = 0: enhancement trainer (trainer.py:269-298): eps only in the divisors, reported norms are plain.
   // eps_in_norms = 1: inpainting trainer (inpainting/trainer/nppc_trainer.py:352-372): w_norms and err_norm carry the
   //                   eps themselves (w_norms = (|w| + eps) / (|e| + eps), err_norm = |e| + eps).
+  // objective != null (ONE workgroup, B <= blockDim.x): also objective = mean_b reconst + lam * mean_{b,i} sm
+  // (trainer.py:300-304 `_calculate_final_objective`), the samples added in index order -- four ATen launches less per step
+  __shared__ double osum[2][16];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  double rec_b = 0.0, sm_b = 0.0;
+  if (b < B) {
   const int KV = K + 1;
   const double* G = Gall + (size_t)b * KV * KV * 2;
   const double en = sqrt(G[(K * KV + K) * 2]);
@@ -475,6 +480,7 @@ __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __rest
     w_norms[b * K + i] = (float)wno;
     const double dsm = wno * wno - pm2;
     sm[b * K + i] = (float)(dsm * dsm);
+    sm_b += (double)(float)(dsm * dsm);
     rec -= pm2;
     // d(pm2)/dw = 2 conj(q) e / (dw^2 de^2) - 2 |q|^2 / (dw^3 de^2) * w / wn ;  d(wno^2)/dw = 2 wn/de^2 * w / wn
     // store unit-weight pieces; the host-provided upstream weights are applied in loss_bwd_coef_kernel
@@ -485,6 +491,18 @@ __global__ void loss_solve_kernel(const double* __restrict__ Gall, float* __rest
     coefE[(b * K + i) * 2 + 1] = -2.0 * qi / (dw * dw * de * de);
   }
   reconst[b] = (float)rec;
+  rec_b = (double)(float)rec;
+  }
+  if (objective) {
+    const double r = wave_sum(rec_b), m = wave_sum(sm_b);
+    if ((threadIdx.x & 63) == 0) { osum[0][threadIdx.x >> 6] = r; osum[1][threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double R = 0.0, M = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { R += osum[0][w]; M += osum[1][w]; }
+      *objective = (float)(R / B) + lam * (float)(M / ((double)B * K));
+    }
+  }
 }
 
 // M1[b][i][i] = -gr_b * A0 + gs * A1 ; M1[b][i][K] = -gr_b * E   (gr_b = dL/d reconst_b, gs = dL/d sm)
@@ -621,7 +639,7 @@ int nppc_loss_solve(const double* G, float* err_norm, float* proj_re, float* pro
                     float* reconst, float* sm, double* coefA, double* coefE, int B, int K, void* stream) {
   if (!G || !err_norm || !coefA || !coefE || K + 1 > KMAX) return NPPC_EBADARG;
   hipLaunchKernelGGL(loss_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, err_norm, proj_re,
-                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, 1e-8, 0);
+                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, 1e-8, 0, 0.f, (float*)nullptr);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }
@@ -633,7 +651,20 @@ int nppc_loss_solve_eps(const double* G, float* err_norm, float* proj_re, float*
                         void* stream) {
   if (!G || !err_norm || !coefA || !coefE || K + 1 > KMAX || !(eps >= 0)) return NPPC_EBADARG;
   hipLaunchKernelGGL(loss_solve_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, G, err_norm, proj_re,
-                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, eps, eps_in_norms);
+                     proj_im, proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, eps, eps_in_norms, 0.f, (float*)nullptr);
+  NPPC_CHECK_LAUNCH();
+  return NPPC_OK;
+}
+
+// ... and the step's objective = mean(reconst) + lam * mean(sm) (trainer.py:300-304) from the same launch: one workgroup,
+// B <= 1024 (NPPC_EUNSUPPORTED beyond: the caller adds the means up itself)
+int nppc_loss_solve_obj(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
+                        float* reconst, float* sm, double* coefA, double* coefE, int B, int K, double eps, int eps_in_norms,
+                        float lam, float* objective, void* stream) {
+  if (!G || !err_norm || !coefA || !coefE || !objective || K + 1 > KMAX || !(eps >= 0)) return NPPC_EBADARG;
+  if (B > 1024) return NPPC_EUNSUPPORTED;
+  hipLaunchKernelGGL(loss_solve_kernel, dim3(1), dim3(round_up(B, 64)), 0, (hipStream_t)stream, G, err_norm, proj_re, proj_im,
+                     proj_mag, w_norms, reconst, sm, coefA, coefE, B, K, eps, eps_in_norms, lam, objective);
   NPPC_CHECK_LAUNCH();
   return NPPC_OK;
 }

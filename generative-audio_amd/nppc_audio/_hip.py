@@ -161,6 +161,7 @@ SIGS = {
     "nppc_adam_step": [P, P, P, P, L, D, D, D, D, D, I, D, P],
     "nppc_adam_step_guarded": [P, P, P, P, L, D, D, D, D, D, I, D, P, I, P, P],
     "nppc_loss_solve_eps": [P, P, P, P, P, P, P, P, P, P, I, I, D, I, P],
+    "nppc_loss_solve_obj": [P, P, P, P, P, P, P, P, P, P, I, I, D, I, F, P, P],
     "nppc_mix_snr": [P, P, P, F, P, P, P, I, I, P],
     "nppc_inpaint_prepare": [P, P, P, I, F, P, P, P, I, I, I, I, I, P],
     "nppc_time_to_spec_mask": [P, P, I, I, I, I, I, I, P],

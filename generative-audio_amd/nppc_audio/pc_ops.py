@@ -83,9 +83,14 @@ class NPPCLoss(torch.autograd.Function):
         pr, pi, pm, wn, sm = f(B, K), f(B, K), f(B, K), f(B, K), f(B, K)
         coefA = torch.empty(B, K, 4, dtype=torch.float64, device=dev)
         coefE = torch.empty(B, K, 2, dtype=torch.float64, device=dev)
-        H.call("nppc_loss_solve_eps", G, err_norm, pr, pi, pm, wn, reconst, sm, coefA, coefE, B, K, float(eps),
-               int(eps_in_norms), s)
-        objective = reconst.mean() + lam * sm.mean()
+        if B <= 1024:        # the objective from the same launch (two means, a product and a sum less on the step's critical chain)
+            objective = torch.empty((), dtype=torch.float32, device=dev)
+            H.call("nppc_loss_solve_obj", G, err_norm, pr, pi, pm, wn, reconst, sm, coefA, coefE, B, K, float(eps),
+                   int(eps_in_norms), float(lam), objective, s)
+        else:
+            H.call("nppc_loss_solve_eps", G, err_norm, pr, pi, pm, wn, reconst, sm, coefA, coefE, B, K, float(eps),
+                   int(eps_in_norms), s)
+            objective = reconst.mean() + lam * sm.mean()
         ctx.save_for_backward(w, gt, pred, coefA, coefE)
         ctx.lam = float(lam)
         ctx.mark_non_differentiable(err_norm, pr, pi, pm, wn, sm)

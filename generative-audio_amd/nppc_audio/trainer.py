@@ -267,6 +267,7 @@ class NPPCAudioTrainer(nn.Module):
         # flush() (train() checks the hand-off time-out counter at every log interval and flushes at the end,
         # save_checkpoint() always flushes).
         self.pipeline_update = False
+        self._seed = None
         self._pending = None
         self._poison = None
 
@@ -305,7 +306,9 @@ class NPPCAudioTrainer(nn.Module):
             reconst_err, objective, log = self.base_step(batch)
             self.flush()                                     # (no-op when the hook already ran)
             self.optimizer.zero_grad()
-            objective.backward()
+            if self._seed is None or self._seed.device != objective.device:
+                self._seed = torch.ones((), dtype=objective.dtype, device=objective.device)   # d objective / d objective, built once
+            objective.backward(self._seed)                   # (backward() alone fills a fresh ones tensor every step)
             ok = True
         finally:
             net.flat_grad_only = False

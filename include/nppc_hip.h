@@ -302,6 +302,11 @@ int nppc_loss_solve(const double* G, float* err_norm, float* proj_re, float* pro
 int nppc_loss_solve_eps(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
                         float* reconst, float* sm, double* coefA, double* coefE, int B, int K, double eps, int eps_in_norms,
                         void* stream);
+/* the same, which also leaves the step's objective = mean_b reconst + lam * mean_{b,i} sm (trainer.py:300-304) in objective[0]:
+ * one workgroup, B <= 1024 (NPPC_EUNSUPPORTED beyond) */
+int nppc_loss_solve_obj(const double* G, float* err_norm, float* proj_re, float* proj_im, float* proj_mag, float* w_norms,
+                        float* reconst, float* sm, double* coefA, double* coefE, int B, int K, double eps, int eps_in_norms,
+                        float lam, float* objective, void* stream);
 int nppc_loss_bwd_coef(const double* coefA, const double* coefE, const float* grec, float gobj_over_B, float gsm, double* M1,
                        int B, int K, void* stream);
 /* the same with the upstream gradient of the objective read from DEVICE memory (gobj, one float): the coefficients are

@@ -73,7 +73,9 @@ def test_cirm_build_decompress_dropband(name):
 
 # error / max|reference| of the intermediate taps; measured worst over the fixtures (profiles/r03_parity_errors.json):
 # fp32 att 8.8e-5 (imag branch: laplace norm of a signed map), fb 8.8e-5, sb 1.1e-6; bf16 att 3.3e-3, fb 7.0e-3, sb 4.8e-3
-TAP_LIMITS = {"fp32": {"att": 3e-4, "fb": 3e-4, "sb": 1e-5}, "bf16": {"att": 1e-2, "fb": 2e-2, "sb": 1.5e-2}}
+# bf16: <= 2 x the measured worst of rounds 3 and 4 (profiles/r04_parity_errors.json: attention 3.3e-3, full band 7.0e-3, sub-band
+# input 4.8e-3)
+TAP_LIMITS = {"fp32": {"att": 3e-4, "fb": 3e-4, "sb": 1e-5}, "bf16": {"att": 6e-3, "fb": 1.4e-2, "sb": 9e-3}}
 
 
 def _restorer(c, precision):
@@ -89,8 +91,8 @@ def _restorer(c, precision):
 
 
 @pytest.mark.parametrize("name,precision,tol", [("g0_tiny", "fp32", 3e-4), ("g1_c1", "fp32", 3e-4),
-                                                ("g2_k5", "fp32", 3e-4), ("g1_c1", "bf16", 3e-2),
-                                                ("g0_tiny", "bf16", 3e-2)])
+                                                ("g2_k5", "fp32", 3e-4), ("g1_c1", "bf16", 2e-2),
+                                                ("g0_tiny", "bf16", 2e-2)])
 def test_restorer_forward_matches_reference(name, precision, tol, record_err):
     z, meta = load(name)
     c = meta["config"]

@@ -63,11 +63,11 @@ PRELU_VECTOR_TOL = 0.2     # the 8 PReLU slopes of a kind as one tensor: error /
 
 def bf16_grad_tol(n):
     """bf16 mode, error / max|grad| vs the fp64 oracle for the well-conditioned tensors (table in DESIGN.md section 2):
-    0.2 for weight / bias / GroupNorm tensors (measured worst: attention 0.155, TCN 1x1 / depthwise / norm 0.11, sub-band
-    LSTM + head 0.042); 0.6 for the PReLU slopes taken one by one: single scalars of 1e-7 .. 1e-6 that are sums over every
-    element of a [B, 512, T'] tensor with heavy cancellation (measured worst 0.50: -1.23e-7 vs -0.61e-7, an absolute error of
-    6e-8 next to slopes of 1.2e-6) -- as ONE tensor per kind they are held to PRELU_VECTOR_TOL like every other family"""
-    return 0.6 if ".prelu" in n else 0.2
+    0.2 for full-band weight / bias / GroupNorm tensors (measured worst over rounds 3 and 4, whose restorer LSTM plans
+    differ: attention 0.185, TCN 1x1 0.176, norms 0.17, depthwise 0.10, output Linear 0.13); 0.08 for the sub-band LSTM + head
+    (0.042); 0.5 for the PReLU slopes taken one by one, each measured against max(|itself|, a quarter of the largest slope
+    gradient of its kind) (0.33; as ONE tensor per kind they are held to PRELU_VECTOR_TOL like every other family)"""
+    return 0.5 if ".prelu" in n else (0.08 if ".sb_model." in n else 0.2)
 
 
 @pytest.mark.parametrize("name,precision", [("g0_tiny", "fp32"), ("g1_c1", "fp32"), ("g2_k5", "fp32"),
@@ -90,10 +90,12 @@ def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
     # (measured values of every run: profiles/r03_parity_errors.json; bf16 limits = 2 x the measured worst)
     tol = 5e-4 if fp32 else W_MAT_BF16_TOL   # bf16: Gram-Schmidt differences amplify the ~1e-2 bf16 noise of the raw directions
     # bf16 measured (g2_k5): pred_crm 5.8e-3, w_mat 8.8e-2, objective 3.5e-5, reconst_err 8.6e-5
-    record_err("pred_crm", rel(log["pred_crm"].cpu().numpy(), z["pred_crm"]), 3e-4 if fp32 else 2.5e-2)
+    # (bf16 limits tightened in round 4 to <= 2 x the worst measured in rounds 3 and 4, profiles/r04_parity_errors.json:
+    # pred_crm 5.8e-3, objective 3.5e-5, reconst_err 8.7e-5)
+    record_err("pred_crm", rel(log["pred_crm"].cpu().numpy(), z["pred_crm"]), 3e-4 if fp32 else 1.2e-2)
     record_err("w_mat", rel(log["w_mat"].cpu().numpy(), z["log.w_mat"]), tol)
-    record_err("objective_abs", abs(float(obj) - meta["objective_at_step"]["500"]), 2e-5 if fp32 else 1e-3)
-    record_err("reconst_err", rel(log["reconst_err"].cpu().numpy(), z["log.reconst_err"]), 1e-4 if fp32 else 2e-3)
+    record_err("objective_abs", abs(float(obj) - meta["objective_at_step"]["500"]), 2e-5 if fp32 else 1e-4)
+    record_err("reconst_err", rel(log["reconst_err"].cpu().numpy(), z["log.reconst_err"]), 1e-4 if fp32 else 2e-4)
 
     # Every parameter gradient against the oracle's autograd evaluated in FP64.  Why fp64: the reference's own
     # fp32 gradients of the real/imag full-band branches carry up to 1.4e-1 relative error vs fp64 (measured on
@@ -173,7 +175,7 @@ def test_train_step_matches_oracle(name, precision, tmp_path, record_err):
             fam[k] = max(fam.get(k, 0.0), worst[n])
         print(name, "bf16 worst error / max|grad| per well-conditioned family:", {k: f"{v:.2e}" for k, v in sorted(fam.items())})
         for k, v in fam.items():
-            record_err("bf16_grad." + k, v, bf16_grad_tol("x" + (".prelu" if "prelu" in k else "")))
+            record_err("bf16_grad." + k, v, bf16_grad_tol("x" + (".prelu" if "prelu" in k else ".sb_model." if k == "sb_model" else "")))
         record_err("bf16_grad.cos_deficit", 1.0 - cos, 0.01)
         # ... and the way a channel vector is held: the 8 slopes of a kind (prelu1 / prelu2 of the 8 TCN blocks of the branch)
         # as ONE tensor, error / max |grad| over the 8.
