@@ -5,6 +5,7 @@
 // Everything is expressed through per-sample Gram matrices: one streaming pass builds all inner products
 // <a_i, b_n> = sum_t conj(a_i[t]) b_n[t] (fp32 partials, fp64 reduction), a one-thread-per-sample fp64 solve turns
 // them into combination coefficients, and one streaming pass writes the combined vectors.  HBM-bound.
+#include <stdlib.h>
 #include "common.h"
 #include "nppc_hip.h"
 
@@ -187,6 +188,56 @@ __global__ __launch_bounds__(256) void gram4_kernel(VecSet A, VecSet Bs, double*
       atomicAdd(o + (n * KV + i) * 2, r);
       atomicAdd(o + (n * KV + i) * 2 + 1, -m);
     }
+  }
+}
+
+// Two DIFFERENT sets at KV >= 8 (BASELINE config 5: K = 8 directions): 64 complex fp64 accumulators per lane do not fit, so the
+// rows i of the Gram matrix are split over blockIdx.z in NH groups of KV / NH (each group re-reads the second set: still 16-byte
+// loads, against 465 us on the scalar kernel for one 8 x 8 pass at C5)
+template <int KV, int NH>
+__global__ __launch_bounds__(256) void gram4_rows_kernel(VecSet A, VecSet Bs, double* __restrict__ out, int K, long N, long chunk) {
+  constexpr int NI = KV / NH, NP = NI * KV;
+  static_assert(KV % NH == 0, "row groups");
+  __shared__ double red[4][NP * 2];
+  const int b = blockIdx.y, i0 = blockIdx.z * NI;
+  const long t0 = (long)blockIdx.x * chunk;
+  const long t1 = t0 + chunk < N ? t0 + chunk : N;
+  double ar[NP], ai[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) ar[i] = ai[i] = 0.0;
+  for (long t = t0 + 4 * threadIdx.x; t < t1; t += 1024) {
+    float4 xr[NI], xi[NI], yr[KV], yi[KV];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {                         // rows i0 .. i0 + NI - 1 of set A (plain vectors: no gt / pred row here)
+      const float* p = A.v + ((size_t)(b * K + i0 + i) * 2) * N + t;
+      xr[i] = (i0 + i < K) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xi[i] = (i0 + i < K) ? *reinterpret_cast<const float4*>(p + N) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    load_set4<KV>(Bs, K, b, N, t, yr, yi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int n = 0; n < KV; ++n) {
+          const double a_r = f4(xr[i], e), a_i = f4(xi[i], e), b_r = f4(yr[n], e), b_i = f4(yi[n], e);
+          ar[i * KV + n] += a_r * b_r + a_i * b_i;
+          ai[i * KV + n] += a_r * b_i - a_i * b_r;
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double r = wave_sum(ar[i]), m = wave_sum(ai[i]);
+    if (lane == 0) { red[wave][2 * i] = r; red[wave][2 * i + 1] = m; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int p = threadIdx.x, i = i0 + p / KV, n = p % KV;
+    double* o = out + (size_t)b * KV * KV * 2;
+    atomicAdd(o + (i * KV + n) * 2, ((red[0][2 * p] + red[1][2 * p]) + red[2][2 * p]) + red[3][2 * p]);
+    atomicAdd(o + (i * KV + n) * 2 + 1, ((red[0][2 * p + 1] + red[1][2 * p + 1]) + red[2][2 * p + 1]) + red[3][2 * p + 1]);
   }
 }
 
@@ -444,6 +495,81 @@ __global__ __launch_bounds__(64) void gs_bwd_solve_t_kernel(const double* __rest
   }
 }
 
+// ---- the same two solves, ONE WAVE PER SAMPLE (round 4): lane l < K^2 owns Gram entry (m, n) = (l / K, l % K) and forms its term
+// conj(a_m) b_n G_mn of every inner product <sum a_m x_m, sum b_n x_n>; a fixed xor-shuffle tree adds the terms (fp64, same on every
+// run).  The one-thread-per-sample kernels above walk ~K^2 (K+1) / 2 dependent complex products one after the other (16.7 / 18.7 us
+// for 32 5 x 5 problems; 320 / 271 us for 8 x 8 ones, whose register version does not exist: 3 x 64 complex doubles per thread).
+// Vectors live in LDS as [K] complex doubles; K <= 8 (K^2 <= 64 lanes).
+__device__ __forceinline__ cd wave_csum(cd v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { v.r += __shfl_xor(v.r, o, 64); v.i += __shfl_xor(v.i, o, 64); }
+  return v;
+}
+__global__ __launch_bounds__(64) void gs_solve_wave_kernel(const double* __restrict__ Gall, double* __restrict__ Call,
+                                                           double* __restrict__ Chall, int K, int KV) {
+  __shared__ cd Cs[8][8], Chs[8][8];
+  const int b = blockIdx.x, lane = threadIdx.x, m = lane / K, n = lane % K;
+  const bool on = lane < K * K;
+  const double* Gp = Gall + (size_t)b * KV * KV * 2;
+  const cd g = on ? cd{Gp[(m * KV + n) * 2], Gp[(m * KV + n) * 2 + 1]} : cd{0, 0};
+  for (int i = 0; i < K; ++i) {
+    if (lane < K) Cs[i][lane] = {lane == i ? 1.0 : 0.0, 0.0};
+    __syncthreads();
+    for (int j = 0; j < i; ++j) {
+      const cd t = on ? cmul(cmul(cconj(Cs[i][m]), Chs[j][n]), g) : cd{0, 0};
+      const cd sj = wave_csum(t);                          // sum conj(w) * w_hat_j
+      __syncthreads();
+      if (lane < K) Cs[i][lane] = csub(Cs[i][lane], cmul(sj, Chs[j][lane]));
+      __syncthreads();
+    }
+    const cd t = on ? cmul(cmul(cconj(Cs[i][m]), Cs[i][n]), g) : cd{0, 0};
+    const double nrm = sqrt(wave_csum(t).r);
+    if (lane < K) Chs[i][lane] = {Cs[i][lane].r / nrm, Cs[i][lane].i / nrm};
+    __syncthreads();
+  }
+  double* Co = Call + (size_t)b * KV * KV * 2;
+  double* Cho = Chall + (size_t)b * KV * KV * 2;
+  for (int e = lane; e < KV * KV; e += 64) {
+    const int i = e / KV, mm = e % KV;
+    const bool in = i < K && mm < K;
+    Co[e * 2] = in ? Cs[i][mm].r : 0.0;
+    Co[e * 2 + 1] = in ? Cs[i][mm].i : 0.0;
+    Cho[e * 2] = in ? Chs[i][mm].r : 0.0;
+    Cho[e * 2 + 1] = in ? Chs[i][mm].i : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(64) void gs_bwd_solve_wave_kernel(const double* __restrict__ Gall, const double* __restrict__ Pall,
+                                                               const double* __restrict__ Chall, double* __restrict__ Dall, int K,
+                                                               int KV) {
+  __shared__ cd Chs[8][8], ds[8];
+  const int b = blockIdx.x, lane = threadIdx.x, m = lane / K, n = lane % K;
+  const bool on = lane < K * K;
+  const double* Gp = Gall + (size_t)b * KV * KV * 2;
+  const double* P = Pall + (size_t)b * KV * KV * 2;
+  const double* Chp = Chall + (size_t)b * KV * KV * 2;
+  double* Do = Dall + (size_t)b * KV * KV * 2;
+  const cd g = on ? cd{Gp[(m * KV + n) * 2], Gp[(m * KV + n) * 2 + 1]} : cd{0, 0};
+  if (on) Chs[m][n] = {Chp[(m * KV + n) * 2], Chp[(m * KV + n) * 2 + 1]};
+  for (int e = lane; e < KV * KV * 2; e += 64) Do[e] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < K; ++i) {
+    if (lane < K) ds[lane] = {0, 0};
+    const cd pin = lane < K ? cd{P[(i * KV + lane) * 2], P[(i * KV + lane) * 2 + 1]} : cd{0, 0};   // P[i][n] on lane n
+    __syncthreads();
+    for (int j = i - 1; j >= 0; --j) {
+      cd t = on ? cmul(cmul(cconj(ds[m]), Chs[j][n]), g) : cd{0, 0};
+      if (lane < K) t = cadd(t, cmul(Chs[j][lane], pin));
+      const cd sj = wave_csum(t);
+      __syncthreads();
+      if (lane < K) ds[lane] = csub(ds[lane], cmul(sj, Chs[j][lane]));
+      __syncthreads();
+    }
+    if (lane < K) { Do[(i * KV + lane) * 2] = ds[lane].r; Do[(i * KV + lane) * 2 + 1] = ds[lane].i; }
+    __syncthreads();
+  }
+}
+
 // Loss scalars from the Gram of [w_0..w_{K-1}, e] (KV = K+1), trainer.py:269-298.
 // Also the backward coefficients: dL/dw_i = a_i w_i + b_i e  with upstream weights
 //   dL/d(reconst_b) = gr[b] (+ gobj/B folded in by the host), dL/d(sm_bi) = gs (= gobj*lambda/(B*K)).
@@ -529,6 +655,13 @@ __global__ void loss_bwd_coef_kernel(const double* __restrict__ coefA, const dou
 template <int KV>
 static void launch_gram(const VecSet& A, const VecSet& Bs, int same, double* out, int B, int K, long N, hipStream_t s) {
   auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if constexpr (KV == 8) {
+    if (!same && N % 4 == 0 && al16(A.v) && al16(Bs.v) && !A.gt && !Bs.gt) {     // two sets at K = 8: row groups (registers)
+      const long chunk4 = 1024L * 2;
+      hipLaunchKernelGGL((gram4_rows_kernel<KV, 2>), dim3(ceil_div(N, chunk4), B, 2), dim3(256), 0, s, A, Bs, out, K, N, chunk4);
+      return;
+    }
+  }
   if (N % 4 == 0 && al16(A.v) && al16(A.gt) && al16(A.pred) && al16(Bs.v) && (same || KV <= 7)) {   // (KV > 7, two sets: registers)
     const long chunk4 = 1024L * 2;                     // two iterations of 4 t per lane: 512 workgroups at C2
     dim3 grid4(ceil_div(N, chunk4), B);
@@ -607,7 +740,13 @@ int nppc_gs_solve(const double* G, double* C, double* Ch, int B, int K, int KV, 
   if (!G || !C || !Ch || K > KMAX || KV < K) return NPPC_EBADARG;
   const dim3 grid(ceil_div(B, 64));
   hipStream_t s = (hipStream_t)stream;
-  switch (K) {      // register-resident specialisations for the direction counts in use (K = 2..6, 8)
+  static const bool wave_solve = [] { const char* e = getenv("NPPC_GS_WAVE_SOLVE"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (wave_solve && K <= 8) {        // one wave per sample, one lane per Gram entry
+    hipLaunchKernelGGL(gs_solve_wave_kernel, dim3(B), dim3(64), 0, s, G, C, Ch, K, KV);
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
+  switch (K) {      // one thread per sample: register-resident specialisations for K = 2..6, generic beyond
     case 2: hipLaunchKernelGGL(gs_solve_t_kernel<2>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
     case 3: hipLaunchKernelGGL(gs_solve_t_kernel<3>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
     case 4: hipLaunchKernelGGL(gs_solve_t_kernel<4>, grid, dim3(64), 0, s, G, C, Ch, B, KV); break;
@@ -623,6 +762,12 @@ int nppc_gs_bwd_solve(const double* G, const double* P, const double* Ch, double
   if (!G || !P || !Ch || !D || K > KMAX || KV < K) return NPPC_EBADARG;
   const dim3 grid(ceil_div(B, 64));
   hipStream_t s = (hipStream_t)stream;
+  static const bool wave_solve = [] { const char* e = getenv("NPPC_GS_WAVE_SOLVE"); return !(e && e[0] == '0'); }();
+  if (wave_solve && K <= 8) {
+    hipLaunchKernelGGL(gs_bwd_solve_wave_kernel, dim3(B), dim3(64), 0, s, G, P, Ch, D, K, KV);
+    NPPC_CHECK_LAUNCH();
+    return NPPC_OK;
+  }
   switch (K) {
     case 2: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<2>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;
     case 3: hipLaunchKernelGGL(gs_bwd_solve_t_kernel<3>, grid, dim3(64), 0, s, G, P, Ch, D, B, KV); break;

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* __restrict__ X, lo
 }
 
 // g = (dyA + dyB) * leaky'(y);  S[c] += sum g,  S[C + c] += sum g * xhat      (fp64 atomics), xhat = (x - mean) rstd
+// Round 4: the LeakyReLU mask y > 0 is RECOMPUTED from the raw convolution output, y = leaky(x scale + shift) with the very
+// expression bn_act_kernel used, instead of read from the stored activation: one tensor read less in each of the two backward
+// passes (Y is accepted for the ABI and not touched)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dyA, long ldA, const T* __restrict__ dyB,
                                                             long ldB, const T* __restrict__ Y, long ldy,
@@ -415,10 +418,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   __shared__ float red[2][256][8];
   const int cg = C / 8, rl = 256 / cg;
   const int g8 = threadIdx.x % cg, r = threadIdx.x / cg;
-  float s1[8], s2[8], mean[8], rstd[8];
+  float s1[8], s2[8], mean[8], rstd[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     s1[i] = s2[i] = 0.f;
+    sc[i] = ss[g8 * 8 + i];
+    sh[i] = ss[C + g8 * 8 + i];
     mean[i] = ss[2 * C + g8 * 8 + i];
     rstd[i] = ss[3 * C + g8 * 8 + i];
   }
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
   if (r < rl)
     for (long p = p0 + r; p < p1; p += 2 * rl) {          // two rows (6-8 loads of 16 bytes) in flight per thread
-      float av[2][8], bv[2][8], yv[2][8], xv[2][8];
+      float av[2][8], bv[2][8], xv[2][8];
       bool ok[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -435,7 +440,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         if (ok[j]) {
           load8<T>(dyA + q * ldA + g8 * 8, av[j]);
           if (dyB) load8<T>(dyB + q * ldB + g8 * 8, bv[j]);
-          load8<T>(Y + q * ldy + g8 * 8, yv[j]);
           load8<T>(X + q * ldx + g8 * 8, xv[j]);
         }
       }
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             float gq = dyB ? av[j][i] + bv[j][i] : av[j][i];
-            if (!(yv[j][i] > 0.f)) gq *= slope;
+            if (!(xv[j][i] * sc[i] + sh[i] > 0.f)) gq *= slope;
             s1[i] += gq;
             s2[i] += gq * ((xv[j][i] - mean[i]) * rstd[i]);
           }
@@ -482,20 +486,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const int c8 = (int)(i % (unsigned)cg) * 8;
   if (!interior(p, P, H, W)) return;
   const double invn = 1.0 / n;
-  float av[8], bv[8], yv[8], xv[8], dv[8];
+  float av[8], bv[8], xv[8], dv[8];
   load8<T>(dyA + p * ldA + c8, av);
   if (dyB) {
     load8<T>(dyB + p * ldB + c8, bv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) av[k] += bv[k];
   }
-  load8<T>(Y + p * ldy + c8, yv);
   load8<T>(X + p * ldx + c8, xv);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c8 + k;
     float gq = av[k];
-    if (!(yv[k] > 0.f)) gq *= slope;
+    if (!(xv[k] * ss[c] + ss[C + c] > 0.f)) gq *= slope;
     const float xh = (xv[k] - ss[2 * C + c]) * ss[3 * C + c];
     const float m1 = (float)(S[c] * invn), m2 = (float)(S[C + c] * invn);
     dv[k] = ss[c] * (gq - m1 - xh * m2);

@@ -426,6 +426,7 @@ int nppc_bn_finalize(const double* st, const float* gamma, const float* beta, fl
                      double n, float eps, float momentum, int train, void* stream);
 int nppc_bn_act(int prec, const void* X, long ldx, void* Y, long ldy, const float* ss, int C, int B, int H, int W, float slope,
                 void* stream);
+/* (Y is accepted and not read since round 4: the LeakyReLU mask is recomputed from X with bn_act's own expression) */
 int nppc_bn_bwd(int prec, const void* dyA, long ldA, const void* dyB, long ldB, const void* Y, long ldy, const void* X, long ldx,
                 const float* ss, double* S, void* dX, long lddx, float* dgamma, float* dbeta, int C, int B, int H, int W,
                 float slope, void* stream);
