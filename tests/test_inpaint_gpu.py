@@ -58,7 +58,9 @@ def q(x, dtype):
 
 
 @pytest.mark.parametrize("pname,prec,dtype,tol", PRECS)
-@pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 9, 13, 64, 64, 3), (1, 6, 37, 128, 192, 3), (3, 5, 7, 64, 5, 1)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 9, 13, 64, 64, 3), (1, 6, 37, 128, 192, 3), (3, 5, 7, 64, 5, 1),
+                                               # Np % 128 == 0: the 128-column tile (round 4: it had no unit test), long K
+                                               (2, 9, 13, 64, 128, 3), (1, 5, 21, 256, 256, 3), (2, 4, 6, 128, 128, 1)])
 def test_conv_forward_input_gradient_weight_gradient(pname, prec, dtype, tol, B, H, W, Cin, Cout, ks):
     from nppc_audio import _hip as Hh
     g = torch.Generator().manual_seed(B * 100 + Cin + Cout)
