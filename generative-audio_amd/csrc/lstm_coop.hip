@@ -95,6 +95,16 @@ __device__ __forceinline__ void coop_prime(typename Frag<T>::type (&pre)[DEPTH -
     }
 }
 
+// Row padding of the LDS A tiles (bf16 elements).  An MFMA A fragment is one ds_read_b128 per lane: lane = (row n, 16-byte chunk
+// q) at n * stride + 16 q.  CDNA4 serves a ds_read_b128 in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31},
+// ... -- and a group is conflict-free when (n * s + q) mod 16 is a bijection on it, s = stride / 16 bytes: true for s = 2 (mod 4),
+// for NO odd s.  With "+ 8 elements" (s = 1) rows 12 (q = 0) and 11 (q = 1) meet in every group: every A read takes two LDS
+// cycles (SQ_LDS_BANK_CONFLICT = 0.48 of SQ_LDS_IDX_ACTIVE in all three recurrent kernels); with + 16 the conflicts are gone
+// (0.06) -- and the kernels take the SAME time (forwards +-0.5 %, the K-split backward 1.5 % SLOWER: its 8-byte gate stores
+// conflict more): the LDS array is not what these kernels wait for (profiles/r04_lstm_sq_counters.txt).  Default stays 8.
+#ifndef COOP_APAD
+#define COOP_APAD 8
+#endif
 #ifndef CF_H2_LATE
 #define CF_H2_LATE 1  // forward: the partner's h2 slice is polled / requested behind layer 1's first GEMM (0 = round 3: at the top of the step)
 #endif
@@ -267,7 +277,7 @@ __global__ __launch_bounds__((384 / G / 16) * 64) void lstm2_coop_fwd_kernel(Coo
 #endif
   constexpr int H = 384, HC = H / G, NW = HC / 16, NT = NW * 64, MC = 16 * MT;
   constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int RS = 2 * KX + 2 * H + VEC;
+  constexpr int RS = 2 * KX + 2 * H + (sizeof(T) == 2 ? COOP_APAD : VEC);
   constexpr int OX0 = 0, OX1 = KX, OH1 = 2 * KX, OH2 = 2 * KX + H;
   constexpr int NKX = KX / 32, NKH = H / 32;
   constexpr int nk1 = NKX + NKH, nk2 = 2 * NKH;
@@ -705,7 +715,7 @@ __device__ __forceinline__ void cb_gemm(f32x4 (&acc)[2][2], const bf16_t* a_lane
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd_kernel(CoopBwdArgs a) {
   typedef bf16_t T;
   constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
-  constexpr int RSA = CB_K4 + 8;                            // A tile row stride (elements)
+  constexpr int RSA = CB_K4 + COOP_APAD;                            // A tile row stride (elements)
   constexpr int TPR = NT / MC, UPT = HC / TPR;              // 24 threads per row, 8 units per thread
   constexpr int HALF_CH = MC * CB_KC * 2 / 16;              // 16-byte chunks of one dgates half (3072)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1085,7 +1095,7 @@ template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd2_kernel(CoopBwd2Args a) {
   typedef bf16_t T;
   constexpr int MC = CB_MC, H = CB_H, HC = CB_HC, KX = CB_KX, NT = CB_NT;
-  constexpr int RSA = CB_KC + 8;                            // A tile row stride (elements): own gate columns only
+  constexpr int RSA = CB_KC + COOP_APAD;                            // A tile row stride (elements): own gate columns only
   constexpr int TPR = NT / MC, UPT = HC / TPR;              // 24 threads per row, 8 units per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Abuf = reinterpret_cast<T*>(smem_raw);                                          // [32][RSA]   own dgates
@@ -1557,7 +1567,7 @@ template <bool HEAD>
 __global__ __launch_bounds__(CB_NT) void lstm2_coop_bwd4_kernel(CoopBwd2Args a) {
   typedef bf16_t T;
   constexpr int MC = C4_MC, H = CB_H, HC = C4_HC, KX = CB_KX, NT = CB_NT;
-  constexpr int RSA = C4_KC + 8;                            // A tile row stride (elements): own gate columns only
+  constexpr int RSA = C4_KC + COOP_APAD;                            // A tile row stride (elements): own gate columns only
   constexpr int TPR = NT / MC, UPT = HC / TPR;              // 12 threads per row, 8 units per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Abuf = reinterpret_cast<T*>(smem_raw);                                          // [64][RSA]   own dgates
@@ -2014,7 +2024,7 @@ static int coop_fits(const void* kernel, int threads, size_t smem, int grid, int
 template <typename T, int G, int MT, bool TRAIN, bool HEAD = false>
 static int launch_coop(CoopArgs a, size_t xch_bytes, hipStream_t s) {
   constexpr int KX = 64, H = 384, MC = 16 * MT;
-  constexpr int RS = 2 * KX + 2 * H + 16 / (int)sizeof(T);
+  constexpr int RS = 2 * KX + 2 * H + (sizeof(T) == 2 ? COOP_APAD : 16 / (int)sizeof(T));
   size_t smem = (size_t)MC * RS * sizeof(T) + (TRAIN ? (size_t)2 * MC * (H / G) * sizeof(T) : 0) +
                 (MT > 3 ? (size_t)8 * (H / G) * sizeof(float) : 0);
   if (smem < 84 * 1024) smem = 84 * 1024;            // > half a CU's LDS: at most one workgroup per CU
@@ -2150,7 +2160,7 @@ int nppc_lstm2_bwd_coop(const void* g1, const void* g2, const void* c1, const vo
   if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * CB_KC * 2) return NPPC_EBADARG;
   CoopBwdArgs a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters};
   hipStream_t s = (hipStream_t)stream;
-  constexpr size_t smem = (size_t)CB_MC * (CB_K4 + 8) * 2 + (size_t)2 * CB_MC * CB_HC * 4;
+  constexpr size_t smem = (size_t)CB_MC * (CB_K4 + COOP_APAD) * 2 + (size_t)2 * CB_MC * CB_HC * 4;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm2_coop_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)smem) != hipSuccess)
@@ -2189,7 +2199,7 @@ static int bwd_coop2_impl(const void* g1, const void* g2, const void* c1, const 
   if (xch_bytes < (long)clusters * 2 * 2 * 2 * CB_MC * C2_XW * 2) return NPPC_EBADARG;
   CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dyt, whT};
   hipStream_t s = (hipStream_t)stream;
-  constexpr size_t smem = (size_t)CB_MC * (CB_KC + 8) * 2 + (size_t)4 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
+  constexpr size_t smem = (size_t)CB_MC * (CB_KC + COOP_APAD) * 2 + (size_t)4 * CB_MC * CB_HC * 4 + (size_t)CB_MC * 32 * 4 +
                           (size_t)(CB_HC + CB_MC) * 16 * 2;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
   const void* k = dyt ? reinterpret_cast<const void*>(lstm2_coop_bwd2_kernel<true>)
@@ -2239,7 +2249,7 @@ int nppc_lstm2_bwd_coop4(const void* g1, const void* g2, const void* c1, const v
   if (xch_bytes < (long)clusters * C4_XCH) return NPPC_EBADARG;
   CoopBwd2Args a{g1, g2, c1, c2, dh2, wb1, wb2, dx, dg1, dg2, xch, flags, N, Tn, clusters, dh2 ? nullptr : dyt, dh2 ? nullptr : whT};
   hipStream_t s = (hipStream_t)stream;
-  constexpr size_t smem = (size_t)C4_MC * (C4_KC + 8) * 2 + (size_t)4 * C4_MC * C4_HC * 4 + (size_t)C4_MC * 16 * 4 +
+  constexpr size_t smem = (size_t)C4_MC * (C4_KC + COOP_APAD) * 2 + (size_t)4 * C4_MC * C4_HC * 4 + (size_t)C4_MC * 16 * 4 +
                           (size_t)(C4_HC + C4_MC) * 16 * 2;
   static_assert(smem <= 160 * 1024 && smem > 80 * 1024, "one workgroup per CU");
   const bool head = !dh2;

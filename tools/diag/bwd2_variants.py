@@ -4,14 +4,14 @@
 import glob, os, subprocess, sys, time
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 VARIANTS = {"base": [], "g4_d4": ["-DC4_DEPTH=4"], "g4_d6": ["-DC4_DEPTH=6"], "g4_d8": ["-DC4_DEPTH=8"], "g4_d10": ["-DC4_DEPTH=10"],
-            "g4_d8_nodg_nofetch": ["-DC4_DEPTH=8", "-DC2_NO_DG", "-DC2_NO_FETCH"]}       # "g4*": the four-CU kernel (NPPC_LSTM_BWD_G4=1)
+            "apad16": ["-DCOOP_APAD=16"], "g4_d8_nodg_nofetch": ["-DC4_DEPTH=8", "-DC2_NO_DG", "-DC2_NO_FETCH"]}       # "g4*": the four-CU kernel (NPPC_LSTM_BWD_G4=1)
 R02_REV = "HEAD"        # "r02" variant = lstm_coop.hip of that commit for A/B on one box
 so = lambda n: os.path.join(root, "tools", "diag", f"libv_{n}.so")
 if "--build" in sys.argv:
     csrc = os.path.join(root, "generative-audio_amd", "csrc")
     objs = [os.path.join(root, "generative-audio_amd", "build", os.path.basename(f)[:-4] + ".o") for f in sorted(glob.glob(csrc + "/*.hip"))
             if not f.endswith("lstm_coop.hip")]
-    for n, flags in VARIANTS.items():
+    for n, flags in [(n, f) for n, f in VARIANTS.items() if not [a for a in sys.argv[1:] if a in VARIANTS] or n in sys.argv]:
         o = f"/tmp/lstm_coop_{n}.o"
         src = os.path.join(csrc, "lstm_coop.hip")
         if n == "r02":

@@ -14,7 +14,7 @@ VARIANTS = {"base": [], "nocell": ["-DCF_NO_CELL"], "nobar": ["-DCF_NO_BAR"], "n
             "ag2_apf0": ["-DCF_AG=2", "-DCF_APF=0"], "ag2_apf1": ["-DCF_AG=2", "-DCF_APF=1"],
             "ag1_apf1": ["-DCF_AG=1", "-DCF_APF=1"], "ag1_apf2": ["-DCF_AG=1", "-DCF_APF=2"],
             # h2 hand-off polled / requested at the top of the step (round 3) or behind layer 1's first GEMM (round 4)
-            "r3": ["-DCF_AG=2", "-DCF_APF=0", "-DCF_H2_LATE=0"], "h2top_ag1_apf1": ["-DCF_AG=1", "-DCF_APF=1", "-DCF_H2_LATE=0"]}
+            "apad16": ["-DCOOP_APAD=16"], "r3": ["-DCF_AG=2", "-DCF_APF=0", "-DCF_H2_LATE=0"], "h2top_ag1_apf1": ["-DCF_AG=1", "-DCF_APF=1", "-DCF_H2_LATE=0"]}
 so = lambda n: os.path.join(root, "tools", "diag", f"libf_{n}.so")
 if "--build" in sys.argv:
     csrc = os.path.join(root, "generative-audio_amd", "csrc")
