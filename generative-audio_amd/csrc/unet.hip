@@ -270,6 +270,158 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
   }
 }
 
+// LDS-DMA ring variant of conv_tiled_kernel (bf16, round 4): 256 pixel rows x BN channels per workgroup, 512 threads = 4 x 2
+// waves (wave tile 64 x BN/2), a ring of STAGES stages of one 128-byte K slice of one tap.  Operands go global -> LDS by
+// `global_load_lds_dwordx4` (no staging registers, no ds_write), issued two stages ahead of the stage being multiplied; with the
+// register-staged kernel above a stage cost the memory latency (one stage of prefetch is all hipcc's wait-count pass leaves in
+// flight, and a hand-counted REGISTER ring is not safe: the register allocator may copy a destination that is still in flight,
+// tools/check/asm_rings.py).  An LDS-DMA has no register destination; its completion is counted by hand (`s_waitcnt vmcnt(N)`,
+// N = DMA instructions this wave issued after the stage it needs; vector-memory operations retire in order).
+// A DMA instruction moves 1 KB = 8 LDS rows of 128 B; lane l fills physical 16-byte slot (l & 7) of row (l >> 3), so it FETCHES
+// the logical chunk (l & 7) ^ (row & 7): the LDS image is the XOR-swizzled one conv_tiled_kernel's fragment reads expect
+// (conflict-free under the ds_read_b128 lane groups of CDNA4).  Source rows are clamped to the last pixel row (rows >= P are
+// never stored), so the guard rows the 128-row kernel needs are enough.
+template <int BN, int STAGES>
+__global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
+  typedef bf16_t T;
+  typedef typename Frag<T>::type frag;
+  constexpr int BM = 256, NJ = BN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 1024 / 8, NB = B_BYTES / 1024 / 8, NDMA = NA + NB;      // 1 KB pieces per wave and stage
+  static_assert(NB >= 1 && STAGES >= 2 && STAGES <= 4, "ring shape");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char cd_lds[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;        // XCD-aware order, as in conv_tiled_kernel
+  const unsigned xcd = lin & 7, jj = lin >> 3;
+  const long m0 = (long)((jj / gridDim.y) * 8 + xcd) * BM;
+  const int n0 = (int)(jj % gridDim.y) * BN;
+  if (m0 >= g.P) return;
+  const long ldw = (long)g.ntap * g.Cin;
+  const int kc = g.Cin / 64;
+  const int nstage = g.ntap * kc;
+  const int r_in = lane >> 3, pc = lane & 7, lc = pc ^ r_in;       // (8 * piece is a multiple of 8: row & 7 == r_in)
+  const unsigned char* srcA[NA];
+  const unsigned char* srcB[NB];
+#pragma unroll
+  for (int h = 0; h < NA; ++h) {
+    long row = m0 + 8 * (NA * wave + h) + r_in;
+    row = row < g.P ? row : g.P - 1;
+    srcA[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.A) + row * g.lda + lc * 8);
+  }
+#pragma unroll
+  for (int h = 0; h < NB; ++h)
+    srcB[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.Wp) + (long)(n0 + 8 * (NB * wave + h) + r_in) * ldw + lc * 8);
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)cd_lds;
+  auto dma = [&](const unsigned char* src, unsigned ldst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
+  };
+  int ftap = 0, fcc = 0;                                           // (tap, K slice) of the next stage to request
+  auto fill = [&](int slot) {
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
+    const long aoff = ((long)tap_offset(g, ftap) * g.lda + fcc * 64) * 2;
+    const long boff = ((long)(ftap * kc + fcc) * 64) * 2;
+#pragma unroll
+    for (int h = 0; h < NA; ++h) dma(srcA[h] + aoff, l + (NA * wave + h) * 1024);
+#pragma unroll
+    for (int h = 0; h < NB; ++h) dma(srcB[h] + boff, l + A_BYTES + (NB * wave + h) * 1024);
+    if (++fcc == kc) { fcc = 0; ++ftap; }
+  };
+  auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
+    const int c = 4 * ks + q;
+    return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+  };
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < nstage) fill(s0);
+  int slot = 0;
+  for (int st = 0; st < nstage; ++st) {
+    // stage st has landed once at most NDMA * (stages requested after it) of this wave's DMAs are outstanding
+    const int younger = nstage - 1 - st < STAGES - 2 ? nstage - 1 - st : STAGES - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");      // every wave's pieces of stage st landed; everyone is done reading stage st - 1
+    if (st + STAGES - 1 < nstage) fill(slot == 0 ? STAGES - 1 : slot - 1);          // into the slot stage st - 1 occupied
+    const unsigned char* ta = cd_lds + (size_t)slot * STAGE_BYTES;
+    const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag af[4], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lfrag(ta, wm * 64 + 16 * i + n, ks);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = lfrag(tb, wn * (BN / 2) + 16 * j + n, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bf[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are complete before it reaches the next barrier
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  }
+  T* C = reinterpret_cast<T*>(g.C);
+  float st1[NJ], st2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) st1[j] = st2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = m0 + wm * 64 + 16 * i + 4 * q + r;
+      if (!interior(row, g.P, g.H, g.W)) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (BN / 2) + 16 * j + n;
+        if (col >= g.Cout) continue;
+        float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
+        if (g.scale) {
+          v = v * g.scale[col] + g.shift[col];
+          v = v > 0.f ? v : g.slope * v;
+        }
+        const T o = from_f32<T>(v);
+        C[row * g.ldc + col] = o;
+        const float vo = to_f32<T>(o);
+        st1[j] += vo;
+        st2[j] += vo * vo;
+      }
+    }
+  if (g.stat_part) {
+    // the workgroup covers TWO 128-row statistics tiles (waves wm = 0,1 and wm = 2,3): same sums in the same order as
+    // conv_tiled_kernel's, tile by tile
+    __syncthreads();                                             // the ring is free: every wave has left the main loop
+    float* sp = reinterpret_cast<float*>(cd_lds);                // [wm][stat][BN]
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float a = st1[j], b = st2[j];
+      a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+      b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+      if (q == 0) {
+        sp[(wm * 2 + 0) * BN + wn * (BN / 2) + 16 * j + n] = a;
+        sp[(wm * 2 + 1) * BN + wn * (BN / 2) + 16 * j + n] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int t = tid / BN, c = tid % BN;
+      if (m0 + 128 * t < g.P) {
+        float* pt = g.stat_part + (size_t)(m0 / 128 + t) * 2 * g.ldp + n0 + c;
+        pt[0] = sp[((2 * t) * 2 + 0) * BN + c] + sp[((2 * t + 1) * 2 + 0) * BN + c];
+        pt[g.ldp] = sp[((2 * t) * 2 + 1) * BN + c] + sp[((2 * t + 1) * 2 + 1) * BN + c];
+      }
+    }
+  }
+}
+
 // the per-tile column sums of conv_tiled_kernel -> BatchNorm batch statistics st[c] = sum x, st[C + c] = sum x^2 (fp64), in two
 // small launches with a fixed summation order: slices of the tile list (4 row lanes x 64 channels per workgroup), then the slices
 __global__ __launch_bounds__(256) void bn_parts_reduce_kernel(const float* __restrict__ part, long ntiles, int ldp, int C, int NS,
@@ -1097,6 +1249,44 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
   hipStream_t st = (hipStream_t)stream;
   if (stat_part && !(Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32))) return NPPC_EUNSUPPORTED;   // tiled kernel only
   if (Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32)) {
+    // bf16: the LDS-DMA ring kernel (256-row tiles, one workgroup per CU) is built, bit-identical to the register-staged one
+    // (tests/test_inpaint_gpu.py) and OFF by default: at C3 the 128-channel-tile layers take the same time (+-3 %), the
+    // 64-channel-tile layers 20-28 % longer (one 8-wave workgroup per CU against two 4-wave ones; the operand fetch from L2 /
+    // Infinity Cache, not the depth of the prefetch, bounds these shapes), the step 27.7 against 26.6 ms
+    // (profiles/r04_c3_conv_dma_ab.txt).  NPPC_CONV_DMA=1 runs it where its grid still fills the chip.
+    const char* cd = getenv("NPPC_CONV_DMA");
+    const bool use_dma = cd && cd[0] == '1';
+    if (use_dma && prec == NPPC_PREC_BF16 && Cin % 64 == 0) {
+      const int bn = Np % 128 == 0 ? 128 : 64;
+      const long tiles = (long)ceil_div(g.P, 256) * (Np / bn);
+      const char* mt = getenv("NPPC_CONV_DMA_MIN_TILES");          // (tests lower it to run small, ragged shapes through the ring kernel)
+      if (tiles >= (mt ? atol(mt) : 256L)) {
+        dim3 grid(round_up(ceil_div(g.P, 256), 8), Np / bn);
+        if (bn == 128) {
+          constexpr int smem = 3 * (256 + 128) * 128;
+          static bool attr = false;
+          if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    smem) != hipSuccess)
+              return NPPC_ELAUNCH;
+            attr = true;
+          }
+          hipLaunchKernelGGL((conv_dma_kernel<128, 3>), grid, dim3(512), smem, st, g);
+        } else {
+          constexpr int smem = 3 * (256 + 64) * 128;
+          static bool attr = false;
+          if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    smem) != hipSuccess)
+              return NPPC_ELAUNCH;
+            attr = true;
+          }
+          hipLaunchKernelGGL((conv_dma_kernel<64, 3>), grid, dim3(512), smem, st, g);
+        }
+        NPPC_CHECK_LAUNCH();
+        return NPPC_OK;
+      }
+    }
     if (Np % 128 == 0) {
       dim3 grid(round_up(ceil_div(g.P, 128), 8), Np / 128);
       if (prec == NPPC_PREC_BF16) hipLaunchKernelGGL((conv_tiled_kernel<bf16_t, 128>), grid, dim3(256), 0, st, g);

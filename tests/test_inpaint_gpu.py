@@ -57,6 +57,47 @@ def q(x, dtype):
     return x.to(dtype).float()
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 9, 13, 64, 64, 3), (1, 6, 37, 128, 192, 3), (2, 9, 13, 64, 128, 3), (1, 5, 21, 256, 256, 3),
+                                               (2, 4, 6, 128, 128, 1), (3, 40, 37, 64, 64, 3), (1, 30, 61, 128, 100, 3),
+                                               (4, 126, 126, 64, 64, 3)])
+def test_conv_lds_dma_ring_kernel_equals_register_staged_kernel(B, H, W, Cin, Cout, ks, monkeypatch):
+    """csrc/unet.hip conv_dma_kernel (bf16: 256-row tiles, LDS-DMA ring with hand-counted waits) against conv_tiled_kernel:
+    the same products accumulated in the same order -> bit-identical outputs and per-tile statistics, on ragged pixel counts
+    (last 256-row tile partly / wholly behind P), one to nine taps, K of 1 to 36 stages, both tile widths, folded BatchNorm."""
+    from nppc_audio import _hip as Hh
+    prec, dtype = Hh.PREC_BF16, torch.bfloat16
+    g = torch.Generator().manual_seed(B * 100 + Cin + Cout + H)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g) * 0.1
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    Np = (Cout + 63) // 64 * 64
+    nt = ks * ks
+    wf = torch.empty(Np * nt * Cin, dtype=dtype, device="cuda")
+    wb = torch.empty(Cin * nt * Np, dtype=dtype, device="cuda")
+    s = Hh.stream()
+    Hh.call("nppc_conv_pack", prec, w.cuda(), wf, wb, Cout, Cin, ks, Np, Cin, Cin, Np, s)
+    X = Halo(B, H, W, Cin, dtype).put(x)
+    ntiles = (X.P + 127) // 128
+    out = {}
+    for name, min_tiles in (("tiled", "1000000000"), ("dma", "1")):
+        monkeypatch.setenv("NPPC_CONV_DMA", "1")
+        monkeypatch.setenv("NPPC_CONV_DMA_MIN_TILES", min_tiles)
+        Y, Y2 = Halo(B, H, W, Np, dtype), Halo(B, H, W, Np, dtype)
+        part = torch.full((ntiles * 2 * Np,), float("nan"), dtype=torch.float32, device="cuda")
+        Hh.call("nppc_conv_fwd_stats", prec, X.t, Cin, wf, Y.t, Np, b.cuda(), B, H, W, Cin, Cout, Np, ks, part, s)
+        Hh.call("nppc_conv_fwd", prec, X.t, Cin, wf, Y2.t, Np, b.cuda(), sc.cuda(), sh.cuda(), 0.2, B, H, W, Cin, Cout, Np, ks, s)
+        torch.cuda.synchronize()
+        assert Y.halo_is_zero() and Y2.halo_is_zero()
+        out[name] = (Y, Y2, part)
+    ref = F.conv2d(x, q(w, dtype), b, padding=ks // 2)
+    assert rel(out["dma"][0].get(Cout), ref) < 8e-3
+    assert torch.equal(out["dma"][0].t, out["tiled"][0].t)
+    assert torch.equal(out["dma"][1].t, out["tiled"][1].t)
+    assert torch.equal(out["dma"][2], out["tiled"][2])            # (no NaN left: every tile of every column was written)
+    assert not torch.isnan(out["dma"][2]).any()
+
+
 @pytest.mark.parametrize("pname,prec,dtype,tol", PRECS)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 9, 13, 64, 64, 3), (1, 6, 37, 128, 192, 3), (3, 5, 7, 64, 5, 1),
                                                # Np % 128 == 0: the 128-column tile (round 4: it had no unit test), long K
