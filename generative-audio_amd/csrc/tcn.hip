@@ -302,7 +302,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
     gn_mr = (float)m * gn_rstd;
     gnv = g.gnv + (size_t)z * g.strideGnv;
   }
-  if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_GN || EPI == EPI_MASK_POS) {
+  constexpr bool HAS_RES = EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_GN || EPI == EPI_MASK_POS;
+  // round 4: the plain / PReLU + statistics / ReLU epilogues take the same coalesced route (conv1x1 forward, dA2 of the backward,
+  // the fc layer: 64 two-byte stores per lane were 12-15 of a launch's 38 us, profiles/r04_nt_variants.txt)
+  // (bf16 only: in fp32 the compiler contracts the sum of squares differently in the two layouts, 4e-9 relative -- the parity mode
+  // keeps the numbers of rounds 1-3 bit for bit)
+  constexpr bool STAGED_PLAIN = sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_PRELU_STATS || EPI == EPI_RELU);
+  if constexpr (HAS_RES || STAGED_PLAIN) {
     if (g.staged) {
       // Coalesced epilogue.  In the accumulator layout a lane owns 2-byte elements of 32 different (row, column) pairs: the
       // residual came in as 32 dependent 2-byte gathers per lane AFTER the K loop (19 of the sconv product's 59 us) and the
@@ -313,8 +319,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
       constexpr int HALVES = (128 * LD * 4 <= (int)sizeof(lds)) ? 1 : 2;   // BN = 128: two passes of 64 rows
       constexpr int ROWS = 128 / HALVES;
       float* ot = reinterpret_cast<float*>(&lds[0][0]);
-      const T* res = reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes;
+      [[maybe_unused]] const T* res = HAS_RES ? reinterpret_cast<const T*>(g.res) + (size_t)z * g.strideRes : nullptr;
       float csum[VE];
+      float t1 = 0.f, t2 = 0.f;                 // EPI_PRELU_STATS: sums of the stored (rounded) activations
 #pragma unroll
       for (int e = 0; e < VE; ++e) csum[e] = 0.f;
       for (int h = 0; h < HALVES; ++h) {
@@ -328,9 +335,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                ot[((HALVES == 1 ? wm * 64 : 0) + 16 * i + 4 * q + r) * LD + wn * (BN / 2) + 16 * j + n] =
-                    (EPI == EPI_RESIDUAL_GN ? gn_rstd * acc[i][j][r] : acc[i][j][r]) + bv;
+              for (int r = 0; r < 4; ++r) {
+                float pv = (EPI == EPI_RESIDUAL_GN ? gn_rstd * acc[i][j][r] : acc[i][j][r]) + bv;
+                if (EPI == EPI_PRELU_STATS) pv = pv > 0.f ? pv : slope * pv;
+                if (EPI == EPI_RELU) pv = fmaxf(pv, 0.f);
+                ot[((HALVES == 1 ? wm * 64 : 0) + 16 * i + 4 * q + r) * LD + wn * (BN / 2) + 16 * j + n] = pv;
+                if (EPI == EPI_PRELU_STATS) {
+                  // statistics of the stored (rounded, masked) activations, summed per lane in the accumulator layout and in
+                  // the order of the unstaged epilogue: the GroupNorm statistics stay bit-identical to rounds 1-3
+                  const int row = m0 + wm * 64 + 16 * i + 4 * q + r;
+                  const float vo = (cvalid && (row % g.Tp) < g.Tv) ? to_f32<T>(from_f32<T>(pv)) : 0.f;
+                  t1 += vo;
+                  t2 += vo * vo;
+                }
+              }
           }
         }
         __syncthreads();
@@ -341,12 +359,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
           float v[VE], rv[VE];
           const float4 lo = *reinterpret_cast<const float4*>(ot + rl * LD + cc), hi = *reinterpret_cast<const float4*>(ot + rl * LD + cc + 4);
           v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-          load8<T>(res + (size_t)row * g.ldres + col, rv);
+          if constexpr (HAS_RES) load8<T>(res + (size_t)row * g.ldres + col, rv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             float x = v[e];
-            if (EPI == EPI_MASK_POS) { if (!(rv[e] > 0.f)) x = 0.f; }
-            else x += rv[e];
+            if constexpr (HAS_RES) {
+              if (EPI == EPI_MASK_POS) { if (!(rv[e] > 0.f)) x = 0.f; }
+              else x += rv[e];
+            }
             if (!(rvalid && col + e < g.Nv)) x = 0.f;
             v[e] = x;
             csum[e] += to_f32<T>(from_f32<T>(x));
@@ -355,7 +375,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_lds_kernel(GemmArgs g) {
         }
         if (HALVES == 2) __syncthreads();
       }
-      if (EPI != EPI_RESIDUAL_GN && g.colpart) {
+      if (EPI == EPI_PRELU_STATS) {               // one sample per 128-row tile (Tp % 128 == 0): one atomic pair per workgroup
+        const double d1 = wave_sum((double)t1), d2 = wave_sum((double)t2);
+        __syncthreads();                          // (the tile image in LDS is dead; `red` is separate, but keep the phases apart)
+        if (lane == 0) { red[0][wave] = d1; red[1][wave] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+          double* st = g.stats + (size_t)z * g.strideStats + (size_t)(m0 / g.Tp) * 2;
+          atomicAdd(st, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+          atomicAdd(st + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
+      }
+      if (HAS_RES && EPI != EPI_RESIDUAL_GN && g.colpart) {
         // column sums of the stored tile: a thread's chunk column is the same in every pass (256 % CPR == 0); lanes with the
         // same chunk are CPR apart in a wave, the four waves meet in LDS
         __shared__ float cpl[4][BN];
@@ -611,6 +642,12 @@ static int nt_staged() {
   return v;
 }
 
+// NPPC_NT_STAGED_PLAIN=0: the plain / PReLU / ReLU epilogues in the accumulator layout, as in rounds 1-3 (A/B switch)
+static int nt_staged_plain() {                       // (read per call: tests/test_tcn_gpu.py compares the two epilogues in one process)
+  const char* e = getenv("NPPC_NT_STAGED_PLAIN");
+  return (e && e[0] == '0') ? 0 : 1;
+}
+
 static int launch_nt(int prec, int epi, const void* A, long lda, long sA, const void* B, long ldb, long sB, void* C, long ldc,
                      long sC, const float* bias, long sBias, const void* res, long ldres, long sRes, const float* slope,
                      long sSlope, double* stats, long sStats, int R, int N, int K, int Tp, int Tv, int Nv, int relu_in,
@@ -624,7 +661,10 @@ static int launch_nt(int prec, int epi, const void* A, long lda, long sA, const 
   if (K % (32 * ksplit)) return NPPC_EUNSUPPORTED;
   GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, bias, sBias, res, ldres, sRes, slope, sSlope, stats, sStats,
              R, N, K / ksplit, Tp, Tv, Nv, relu_in, ksplit, nullptr, 0, 1.0, 0.f,
-             (res && ldc % 8 == 0 && ldres % 8 == 0 && nt_staged()) ? 1 : 0, colpart, (long)(R / 128) * N};
+             ((res ? (ldres % 8 == 0 && nt_staged())
+                   : ((epi == EPI_PLAIN || epi == EPI_PRELU_STATS || epi == EPI_RELU) && ksplit == 1 && nt_staged_plain())) &&
+              ldc % 8 == 0) ? 1 : 0,
+             colpart, (long)(R / 128) * N};
   hipStream_t s = (hipStream_t)stream;
   const int bk = prec == NPPC_PREC_BF16 ? 64 : 32;
   const int lds_path = ((K / ksplit) % bk == 0) ? (N % 128 == 0 ? 128 : 64) : 0;

@@ -303,3 +303,48 @@ def test_gemm_epilogue_leaves_tile_column_sums_of_the_output(prec, epi, N, K):
     with pytest.raises(RuntimeError, match="unsupported"):               # K not a multiple of the bf16 LDS stage: no silent fallback
         H.call("nppc_gemm_nt_colsum", prec, epi, A, K, R * K, W, K, N * K, out1, N, R * N, None, 0, res, N, R * N, R, N, 32, Tp, Tv,
                Nv, Z, cp, H.stream())
+
+
+@pytest.mark.parametrize("prec,epi,N,K", [(0, 0, 512, 320), (0, 1, 512, 320), (0, 3, 320, 320), (0, 1, 320, 128), (1, 1, 128, 96), (1, 0, 192, 64)])
+def test_coalesced_plain_prelu_relu_epilogues_equal_the_accumulator_layout_ones(prec, epi, N, K, monkeypatch):
+    """csrc/tcn.hip gemm_nt_lds_kernel, round 4: EPI_PLAIN (0) / EPI_PRELU_STATS (1) / EPI_RELU (3) leave through the LDS tile
+    image as 16-byte row chunks (NPPC_NT_STAGED_PLAIN, default on) -- the same values, masks and GroupNorm statistics, bit for
+    bit, as the accumulator-layout epilogue (64 two-byte stores per lane), and both equal the torch product."""
+    from nppc_audio import _hip as H
+    Z, B, Tp, Tv, Nv = 3, 2, 256, 200, N - 7
+    R = B * Tp
+    dt = H.dtype_of(prec)
+    g = torch.Generator().manual_seed(N + K + epi)
+    A = torch.randn(Z, R, K, generator=g).to(dt).cuda()
+    W = (torch.randn(Z, N, K, generator=g) * 0.1).to(dt).cuda()
+    bias = (torch.randn(Z, N, generator=g) * 0.1).cuda()
+    slope = torch.tensor([0.25, 0.1, -0.3]).cuda()
+    outs, stats = [], []
+    for sw in ("0", "1"):
+        monkeypatch.setenv("NPPC_NT_STAGED_PLAIN", sw)
+        out = torch.full((Z, R, N), float("nan"), dtype=dt, device="cuda")
+        st = torch.zeros(Z, B, 2, dtype=torch.float64, device="cuda")
+        H.call("nppc_gemm_nt", prec, epi, A, K, R * K, W, K, N * K, out, N, R * N, bias, N, None, 0, 0, slope if epi == 1 else None,
+               1, st if epi == 1 else None, B * 2, R, N, K, Tp, Tv, Nv, 0, Z, 1, H.stream())
+        torch.cuda.synchronize()
+        outs.append(out)
+        stats.append(st)
+    assert torch.equal(outs[0], outs[1])
+    if prec == 0:
+        assert torch.equal(stats[0], stats[1])     # (sums of bf16 values and of their squares are exact in fp64: order-free)
+    else:                                          # fp32 keeps the accumulator-layout epilogue (the switch changes nothing); the
+        # workgroups of a sample add their fp64 partials in arrival order
+        assert float(((stats[0] - stats[1]) / stats[1].abs().clamp_min(1.0)).abs().max()) < 1e-12
+    ref = torch.einsum("zrk,znk->zrn", A.double(), W.double()) + bias.double()[:, None, :]
+    if epi == 1:
+        ref = torch.where(ref > 0, ref, slope.double()[:, None, None] * ref)
+    if epi == 3:
+        ref = ref.clamp_min(0)
+    ref = ref.view(Z, B, Tp, N)
+    ref[:, :, Tv:] = 0
+    ref[..., Nv:] = 0
+    got = outs[1].double().view(Z, B, Tp, N)
+    assert float((got - ref).abs().max()) < (2e-2 if prec == 0 else 2e-5) * float(ref.abs().max())
+    if epi == 1:
+        want = torch.stack([got.sum((2, 3)), (got * got).sum((2, 3))], -1)
+        assert float(((stats[1] - want) / want.abs().clamp_min(1.0)).abs().max()) < 1e-5
