@@ -272,10 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
 
 // LDS-DMA ring variant of conv_tiled_kernel (bf16, round 4): 256 pixel rows x BN channels per workgroup, 512 threads = 4 x 2
 // waves (wave tile 64 x BN/2), a ring of STAGES stages of one 128-byte K slice of one tap.  Operands go global -> LDS by
-// `global_load_lds_dwordx4` (no staging registers, no ds_write), issued two stages ahead of the stage being multiplied; with the
-// register-staged kernel above a stage cost the memory latency (one stage of prefetch is all hipcc's wait-count pass leaves in
-// flight, and a hand-counted REGISTER ring is not safe: the register allocator may copy a destination that is still in flight,
-// tools/check/asm_rings.py).  An LDS-DMA has no register destination; its completion is counted by hand (`s_waitcnt vmcnt(N)`,
+// `global_load_lds_dwordx4` (no staging registers, no ds_write), two stages in flight while one is read (a hand-counted REGISTER
+// ring is not safe: the register allocator may copy a destination that is still in flight, tools/check/asm_rings.py).  An LDS-DMA has no register destination; its completion is counted by hand (`s_waitcnt vmcnt(N)`,
 // N = DMA instructions this wave issued after the stage it needs; vector-memory operations retire in order).
 // A DMA instruction moves 1 KB = 8 LDS rows of 128 B; lane l fills physical 16-byte slot (l & 7) of row (l >> 3), so it FETCHES
 // the logical chunk (l & 7) ^ (row & 7): the LDS image is the XOR-swizzled one conv_tiled_kernel's fragment reads expect
@@ -340,34 +338,71 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s0 = 0; s0 < STAGES - 1; ++s0)
-    if (s0 < nstage) fill(s0);
-  int slot = 0;
-  for (int st = 0; st < nstage; ++st) {
-    // stage st has landed once at most NDMA * (stages requested after it) of this wave's DMAs are outstanding
-    const int younger = nstage - 1 - st < STAGES - 2 ? nstage - 1 - st : STAGES - 2;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");      // every wave's pieces of stage st landed; everyone is done reading stage st - 1
-    if (st + STAGES - 1 < nstage) fill(slot == 0 ? STAGES - 1 : slot - 1);          // into the slot stage st - 1 occupied
+  // Software pipeline (round 4, second version): fragments are read into registers HALF A STAGE ahead of their MFMAs (set 0 holds
+  // the first 32-deep k-step of a stage, set 1 the second), so the matrix instructions of a half wait for nothing that was
+  // issued in that half:
+  //   half 1:  read set 1 <- (st, k-step 1)                      | 16 MFMAs on set 0 = (st, k-step 0)
+  //   half 2:  wait for this wave's DMA pieces of stage st+1, lgkmcnt(0) (set 1 has landed; the wave has read all of stage st),
+  //            barrier  -> stage st+1 visible to everyone, slot of stage st free: refill it with stage st+3 (three slots: two
+  //            stages in flight while one is read)
+  //            read set 0 <- (st+1, k-step 0)                    | 16 MFMAs on set 1 = (st, k-step 1)
+  // One barrier per stage, as before.  The sizing builds said where the register-staged kernel loses: with NO operand fetch
+  // behind its first stage it still needs 0.82 of its time (a deep layer: 0.207 of 0.252 ms, 2.6x its MFMA time) -- fragment
+  // reads, their waits and the stage barrier between the matrix instructions, not the fetches.
+  constexpr int LGKM0 = 0xC07F;                                   // s_waitcnt lgkmcnt(0); vmcnt / expcnt untouched (gfx9 encoding)
+  auto read_set = [&](frag (&a)[4], frag (&b)[NJ], int slot, int ks) {
     const unsigned char* ta = cd_lds + (size_t)slot * STAGE_BYTES;
     const unsigned char* tb = ta + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      frag af[4], bf[NJ];
+    for (int i = 0; i < 4; ++i) a[i] = lfrag(ta, wm * 64 + 16 * i + n, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = lfrag(ta, wm * 64 + 16 * i + n, ks);
+    for (int j = 0; j < NJ; ++j) b[j] = lfrag(tb, wn * (BN / 2) + 16 * j + n, ks);
+  };
+  auto mma_set = [&](const frag (&a)[4], const frag (&b)[NJ]) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = lfrag(tb, wn * (BN / 2) + 16 * j + n, ks);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+  };
+  static_assert(STAGES == 3, "the pipeline below is written for a ring of three slots");
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(af[i], bf[j], acc[i][j]);
+  for (int s0 = 0; s0 < 3; ++s0)
+    if (s0 < nstage) fill(s0);
+  frag a0[4], b0[NJ], a1[4], b1[NJ];
+  // stage 0: DMAs requested after it: stages 1, 2 (where they exist)
+  if (nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+  else if (nstage == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  read_set(a0, b0, 0, 0);
+  __builtin_amdgcn_s_waitcnt(LGKM0);
+  int slot = 0;
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    // ---- half 1
+    read_set(a1, b1, slot, 1);
+    __builtin_amdgcn_sched_barrier(0);             // the reads go out in front of the matrix instructions, not behind them
+    mma_set(a0, b0);                               // (set 0 was waited for at the end of the previous half: no wait here)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- half 2
+    if (more) {
+      if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // stage st+2 may still be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are complete before it reaches the next barrier
-    slot = slot + 1 == STAGES ? 0 : slot + 1;
+    __builtin_amdgcn_s_waitcnt(LGKM0);             // set 1 landed: this wave has read everything it needs of stage st
+    asm volatile("s_barrier" ::: "memory");        // every wave: stage st+1 landed, slot of stage st no longer read
+#ifndef CONV_DIAG_NOFILL   /* sizing build (timing only): no operand fetch behind the three prologue stages */
+    if (st + 3 < nstage) fill(slot);
+#endif
+    if (more) read_set(a0, b0, nslot, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_set(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    // set 0 has had sixteen MFMAs to land: an explicit wait HERE costs nothing and leaves hipcc's wait-count pass with nothing
+    // pending across the loop edge (without it the pass put lgkmcnt(0) between half 1's reads and its MFMAs: set 1's reads exposed)
+    __builtin_amdgcn_s_waitcnt(LGKM0);
+    slot = nslot;
   }
   T* C = reinterpret_cast<T*>(g.C);
   float st1[NJ], st2[NJ];
