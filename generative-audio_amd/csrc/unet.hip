@@ -364,14 +364,14 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
   };
-  static_assert(STAGES == 3, "the pipeline below is written for a ring of three slots");
+  static_assert(STAGES == 2 || STAGES == 3, "the pipeline below is written for rings of two or three slots");
 #pragma unroll
-  for (int s0 = 0; s0 < 3; ++s0)
+  for (int s0 = 0; s0 < STAGES; ++s0)
     if (s0 < nstage) fill(s0);
   frag a0[4], b0[NJ], a1[4], b1[NJ];
-  // stage 0: DMAs requested after it: stages 1, 2 (where they exist)
-  if (nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-  else if (nstage == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+  // stage 0: DMAs requested after it: stages 1 .. STAGES-1 (where they exist)
+  if (STAGES == 3 && nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+  else if (nstage >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   read_set(a0, b0, 0, 0);
@@ -379,21 +379,21 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
   int slot = 0;
   for (int st = 0; st < nstage; ++st) {
     const bool more = st + 1 < nstage;
-    const int nslot = slot == 2 ? 0 : slot + 1;
+    const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
     // ---- half 1
     read_set(a1, b1, slot, 1);
     __builtin_amdgcn_sched_barrier(0);             // the reads go out in front of the matrix instructions, not behind them
     mma_set(a0, b0);                               // (set 0 was waited for at the end of the previous half: no wait here)
     __builtin_amdgcn_sched_barrier(0);
     // ---- half 2
-    if (more) {
-      if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");      // stage st+2 may still be in flight
+    if (more) {                                    // (two slots: stage st+2 is requested BEHIND the barrier below, nothing is younger)
+      if (STAGES == 3 && st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // stage st+2 may still be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_waitcnt(LGKM0);             // set 1 landed: this wave has read everything it needs of stage st
     asm volatile("s_barrier" ::: "memory");        // every wave: stage st+1 landed, slot of stage st no longer read
 #ifndef CONV_DIAG_NOFILL   /* sizing build (timing only): no operand fetch behind the three prologue stages */
-    if (st + 3 < nstage) fill(slot);
+    if (st + STAGES < nstage) fill(slot);
 #endif
     if (more) read_set(a0, b0, nslot, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -1295,14 +1295,26 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
     // Infinity Cache, not the depth of the prefetch, bounds these shapes), the step 27.7 against 26.6 ms
     // (profiles/r04_c3_conv_dma_ab.txt).  NPPC_CONV_DMA=1 runs it where its grid still fills the chip.
     const char* cd = getenv("NPPC_CONV_DMA");
-    const bool use_dma = cd && cd[0] == '1';
+    const bool use_dma = cd && (cd[0] == '1' || cd[0] == '2');
     if (use_dma && prec == NPPC_PREC_BF16 && Cin % 64 == 0) {
-      const int bn = Np % 128 == 0 ? 128 : 64;
+      // NPPC_CONV_DMA=2: 256-channel tiles (wave tile 64 x 128, two ring slots) where Np allows -- half the LDS bytes and half the
+      // barriers per MFMA of the 128-channel tile
+      const int bn = (cd[1] == '\0' && cd[0] == '1') ? (Np % 128 == 0 ? 128 : 64) : (Np % 256 == 0 ? 256 : (Np % 128 == 0 ? 128 : 64));
       const long tiles = (long)ceil_div(g.P, 256) * (Np / bn);
       const char* mt = getenv("NPPC_CONV_DMA_MIN_TILES");          // (tests lower it to run small, ragged shapes through the ring kernel)
       if (tiles >= (mt ? atol(mt) : 256L)) {
         dim3 grid(round_up(ceil_div(g.P, 256), 8), Np / bn);
-        if (bn == 128) {
+        if (bn == 256) {
+          constexpr int smem = 2 * (256 + 256) * 128;
+          static bool attr = false;
+          if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    smem) != hipSuccess)
+              return NPPC_ELAUNCH;
+            attr = true;
+          }
+          hipLaunchKernelGGL((conv_dma_kernel<256, 2>), grid, dim3(512), smem, st, g);
+        } else if (bn == 128) {
           constexpr int smem = 3 * (256 + 128) * 128;
           static bool attr = false;
           if (!attr) {
