@@ -285,13 +285,24 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
   typedef typename Frag<T>::type frag;
   constexpr int BM = 256, NJ = BN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int NA = A_BYTES / 1024 / 8, NB = B_BYTES / 1024 / 8, NDMA = NA + NB;      // 1 KB pieces per wave and stage
-  static_assert(NB >= 1 && STAGES >= 2 && STAGES <= 4, "ring shape");
+  // Only the second wave of every SIMD (waves 4-7) requests operands: behind the stage barrier the first waves go straight to
+  // their matrix instructions while the second ones spend ~300 cycles on scalar bookkeeping and twelve DMA issues, then multiply
+  // while the first ones wait at the next barrier -- the SIMD's matrix pipe sees one stream after the other instead of two idle
+  // and then two contending (counters on a 512-channel layer: pipe busy 0.33, waves issue-stalled 0.36, 87 scalar instructions per
+  // wave and stage; profiles/r04_c3_conv_counters.txt).  CONV_DMA_PRODUCERS=8: every wave requests its share (first version).
+#ifndef CONV_DMA_PRODUCERS
+#define CONV_DMA_PRODUCERS 4
+#endif
+  constexpr int NPW = BN == 256 ? 8 : CONV_DMA_PRODUCERS;         // (the 256-channel tile has no registers to spare for 16 row pointers)
+  constexpr int NA = A_BYTES / 1024 / NPW, NB = B_BYTES / 1024 / NPW, NDMA = NA + NB;  // 1 KB pieces per producer wave and stage
+  static_assert(NB >= 1 && STAGES >= 2 && STAGES <= 4 && (NPW == 4 || NPW == 8) && 2 * NDMA <= 63, "ring shape");
   extern __shared__ __attribute__((aligned(1024))) unsigned char cd_lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const bool producer = wave >= 8 - NPW;
+  const int pw = producer ? wave - (8 - NPW) : 0;
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;        // XCD-aware order, as in conv_tiled_kernel
   const unsigned xcd = lin & 7, jj = lin >> 3;
   const long m0 = (long)((jj / gridDim.y) * 8 + xcd) * BM;
@@ -305,13 +316,13 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
   const unsigned char* srcB[NB];
 #pragma unroll
   for (int h = 0; h < NA; ++h) {
-    long row = m0 + 8 * (NA * wave + h) + r_in;
+    long row = m0 + 8 * (NA * pw + h) + r_in;
     row = row < g.P ? row : g.P - 1;
     srcA[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.A) + row * g.lda + lc * 8);
   }
 #pragma unroll
   for (int h = 0; h < NB; ++h)
-    srcB[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.Wp) + (long)(n0 + 8 * (NB * wave + h) + r_in) * ldw + lc * 8);
+    srcB[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.Wp) + (long)(n0 + 8 * (NB * pw + h) + r_in) * ldw + lc * 8);
   const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)cd_lds;
   auto dma = [&](const unsigned char* src, unsigned ldst) {
     unsigned keep;
@@ -320,13 +331,14 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
   };
   int ftap = 0, fcc = 0;                                           // (tap, K slice) of the next stage to request
   auto fill = [&](int slot) {
+    if (!producer) return;
     const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
     const long aoff = ((long)tap_offset(g, ftap) * g.lda + fcc * 64) * 2;
     const long boff = ((long)(ftap * kc + fcc) * 64) * 2;
 #pragma unroll
-    for (int h = 0; h < NA; ++h) dma(srcA[h] + aoff, l + (NA * wave + h) * 1024);
+    for (int h = 0; h < NA; ++h) dma(srcA[h] + aoff, l + (NA * pw + h) * 1024);
 #pragma unroll
-    for (int h = 0; h < NB; ++h) dma(srcB[h] + boff, l + A_BYTES + (NB * wave + h) * 1024);
+    for (int h = 0; h < NB; ++h) dma(srcB[h] + boff, l + A_BYTES + (NB * pw + h) * 1024);
     if (++fcc == kc) { fcc = 0; ++ftap; }
   };
   auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
@@ -370,9 +382,11 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
     if (s0 < nstage) fill(s0);
   frag a0[4], b0[NJ], a1[4], b1[NJ];
   // stage 0: DMAs requested after it: stages 1 .. STAGES-1 (where they exist)
-  if (STAGES == 3 && nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-  else if (nstage >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (producer) {                                  // (the other waves learn it from the barrier)
+    if (STAGES == 3 && nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+    else if (nstage >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   asm volatile("s_barrier" ::: "memory");
   read_set(a0, b0, 0, 0);
   __builtin_amdgcn_s_waitcnt(LGKM0);
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
     mma_set(a0, b0);                               // (set 0 was waited for at the end of the previous half: no wait here)
     __builtin_amdgcn_sched_barrier(0);
     // ---- half 2
-    if (more) {                                    // (two slots: stage st+2 is requested BEHIND the barrier below, nothing is younger)
+    if (more && producer) {                        // (two slots: stage st+2 is requested BEHIND the barrier below, nothing is younger)
       if (STAGES == 3 && st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // stage st+2 may still be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1289,17 +1303,19 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
   hipStream_t st = (hipStream_t)stream;
   if (stat_part && !(Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32))) return NPPC_EUNSUPPORTED;   // tiled kernel only
   if (Cin % bk == 0 && (prec == NPPC_PREC_BF16 || prec == NPPC_PREC_F32)) {
-    // bf16: the LDS-DMA ring kernel (256-row tiles, one workgroup per CU) is built, bit-identical to the register-staged one
-    // (tests/test_inpaint_gpu.py) and OFF by default: at C3 the 128-channel-tile layers take the same time (+-3 %), the
-    // 64-channel-tile layers 20-28 % longer (one 8-wave workgroup per CU against two 4-wave ones; the operand fetch from L2 /
-    // Infinity Cache, not the depth of the prefetch, bounds these shapes), the step 27.7 against 26.6 ms
-    // (profiles/r04_c3_conv_dma_ab.txt).  NPPC_CONV_DMA=1 runs it where its grid still fills the chip.
+    // bf16: the LDS-DMA ring kernel (256-row tiles, one workgroup per CU, software-pipelined fragments, producer waves) takes the
+    // layers whose channel count gives 128-wide tiles (default, NPPC_CONV_DMA unset or 3): bit-identical to the register-staged
+    // kernel (tests/test_inpaint_gpu.py), 5-7 % faster on the >= 128-channel layers of C3, step 26.05 -> 25.85 ms.  The
+    // 64-channel tiles stay on the register-staged kernel (the ring kernel is 20-28 % slower there: one 8-wave workgroup per CU
+    // against two 4-wave ones).  NPPC_CONV_DMA=0: register-staged everywhere; 1: ring kernel wherever its grid fills the chip;
+    // 2: as 1 with 256-channel tiles where possible (profiles/r04_c3_conv_dma_ab.txt).
     const char* cd = getenv("NPPC_CONV_DMA");
-    const bool use_dma = cd && (cd[0] == '1' || cd[0] == '2');
+    if (!cd || !cd[0]) cd = "3";
+    const bool use_dma = cd[0] == '1' || cd[0] == '2' || (cd[0] == '3' && Np % 128 == 0);
     if (use_dma && prec == NPPC_PREC_BF16 && Cin % 64 == 0) {
       // NPPC_CONV_DMA=2: 256-channel tiles (wave tile 64 x 128, two ring slots) where Np allows -- half the LDS bytes and half the
       // barriers per MFMA of the 128-channel tile
-      const int bn = (cd[1] == '\0' && cd[0] == '1') ? (Np % 128 == 0 ? 128 : 64) : (Np % 256 == 0 ? 256 : (Np % 128 == 0 ? 128 : 64));
+      const int bn = cd[0] != '2' ? (Np % 128 == 0 ? 128 : 64) : (Np % 256 == 0 ? 256 : (Np % 128 == 0 ? 128 : 64));
       const long tiles = (long)ceil_div(g.P, 256) * (Np / bn);
       const char* mt = getenv("NPPC_CONV_DMA_MIN_TILES");          // (tests lower it to run small, ragged shapes through the ring kernel)
       if (tiles >= (mt ? atol(mt) : 256L)) {
