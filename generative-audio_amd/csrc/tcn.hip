@@ -1153,10 +1153,18 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
   constexpr int KS = BR / 32;                                   // 32-deep MFMA k-steps per stage
   constexpr int A_BYTES = BR * BM * 2, B_BYTES = BR * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int MI = BM / 64;                                   // 16-row tiles per wave (4 waves across M)
-  constexpr int NA = A_BYTES / 1024 / 8;                        // whole 1 KB DMA pieces per wave and stage (A)
-  constexpr int BW = B_BYTES / 8;                               // B bytes per wave and stage: NBF whole pieces + one half piece
+  // TN_DMA_PRODUCERS = 4: only the second wave of every SIMD (waves 4-7) requests operands, twice the pieces each: behind the stage
+  // barrier the first waves go straight to their matrix instructions (round 4, from the convolution ring kernel: csrc/unet.hip).
+  // LSTM weight-gradient shape alone 1.365 -> 1.315 ms, step -0.11 ms in an alternating A/B (profiles/r04_tn_producers_ab.txt);
+  // 8 = every wave requests its share (rounds 2-3).
+#ifndef TN_DMA_PRODUCERS
+#define TN_DMA_PRODUCERS 4
+#endif
+  constexpr int NPW = TN_DMA_PRODUCERS;
+  constexpr int NA = A_BYTES / 1024 / NPW;                      // whole 1 KB DMA pieces per requesting wave and stage (A)
+  constexpr int BW = B_BYTES / NPW;                             // B bytes per requesting wave and stage: NBF whole pieces + one half piece
   constexpr int NBF = BW / 1024, NBH = (BW % 1024) / 512;
-  static_assert(A_BYTES % 8192 == 0 && BW % 512 == 0 && NBH <= 1, "DMA pieces must divide evenly over the 8 waves");
+  static_assert(A_BYTES % (1024 * NPW) == 0 && BW % 512 == 0 && NBH <= 1 && (NPW == 4 || NPW == 8), "DMA pieces must divide evenly over the requesting waves");
   constexpr int NDMA = NA + NBF + NBH;                          // DMA instructions per wave and stage (the vmcnt unit)
   constexpr int NJ = BN / 32;                                   // 16-column tiles per wave (2 waves across N)
   constexpr int ACH = BM * 2 / 32, BCH = BN * 2 / 32;           // 32-byte chunks per row
@@ -1165,6 +1173,8 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, qq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const bool producer = wave >= 8 - NPW;
+  const int pwv = producer ? wave - (8 - NPW) : 0;
 
   // ---- this wave's DMA pieces of a stage.  A: pieces NA*w + h, 1 KB = 2 rows of 512 B.  B: bytes [w*BW, (w+1)*BW) of the
   // stage's B image (rows of BN*2 bytes back to back): NBF whole pieces and, if BW is not a multiple of 1 KB, one half piece
@@ -1173,14 +1183,14 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
   const unsigned char* srcB[NBF + NBH];
 #pragma unroll
   for (int h = 0; h < NA; ++h) {
-    const int o = (NA * wave + h) * 1024 + lane * 16;           // byte offset inside the stage's A image (rows of BM*2 bytes)
+    const int o = (NA * pwv + h) * 1024 + lane * 16;            // byte offset inside the stage's A image (rows of BM*2 bytes)
     const int row = o / (BM * 2);
     const int p = dr_logical(o % (BM * 2), dr_key(row, ACH), ACH);
     srcA[h] = reinterpret_cast<const unsigned char*>(A + (rbaseA + row) * lda + m0) + p;
   }
 #pragma unroll
   for (int h = 0; h < NBF + NBH; ++h) {
-    const int o = wave * BW + h * 1024 + lane * 16;             // byte offset inside the stage's B image
+    const int o = pwv * BW + h * 1024 + lane * 16;              // byte offset inside the stage's B image
     const int row = o / (BN * 2);
     const int p = dr_logical(o % (BN * 2), dr_key(row, BCH), BCH);
     srcB[h] = reinterpret_cast<const unsigned char*>(B + (rbaseB + row) * ldb + n0) + p;
@@ -1198,13 +1208,14 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
                  : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
   };
   auto fill = [&](int slot, long st) {
+    if (!producer) return;
     const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
 #pragma unroll
-    for (int h = 0; h < NA; ++h) dma(srcA[h] + st * strA, l + (NA * wave + h) * 1024);
+    for (int h = 0; h < NA; ++h) dma(srcA[h] + st * strA, l + (NA * pwv + h) * 1024);
 #pragma unroll
-    for (int h = 0; h < NBF; ++h) dma(srcB[h] + st * strB, l + A_BYTES + wave * BW + h * 1024);
+    for (int h = 0; h < NBF; ++h) dma(srcB[h] + st * strB, l + A_BYTES + pwv * BW + h * 1024);
     if constexpr (NBH != 0) {
-      if (lane < 32) dma(srcB[NBF] + st * strB, l + A_BYTES + wave * BW + NBF * 1024);
+      if (lane < 32) dma(srcB[NBF] + st * strB, l + A_BYTES + pwv * BW + NBF * 1024);
     }
   };
   // transposed fragment of k-rows [32 ks + 8 qq, + 8) x 16 columns starting at col0 (ds_read_b64_tr_b16, two 4-row halves)
@@ -1245,10 +1256,13 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ A, long lda,
     // stage st has landed once at most NDMA * (stages issued after it) of this wave's youngest DMAs are outstanding
     const long younger = nstage - 1 - st < STAGES - 2 ? nstage - 1 - st : STAGES - 2;
     static_assert(STAGES <= 5, "the counted waits below cover rings of up to 5 stages");
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(3 * NDMA <= 63, "vmcnt is a six-bit count");
+    if (producer) {                              // (the other waves learn it from the barrier)
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_barrier" ::: "memory");      // every wave's pieces of stage st landed; everyone is done reading stage st - 1
     if (st + STAGES - 1 < nstage) {
       int fs = slot - 1;
