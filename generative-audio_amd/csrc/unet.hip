@@ -270,193 +270,223 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvArgs g) {
   }
 }
 
-// LDS-DMA ring variant of conv_tiled_kernel (bf16, round 4): 256 pixel rows x BN channels per workgroup, 512 threads = 4 x 2
-// waves (wave tile 64 x BN/2), a ring of STAGES stages of one 128-byte K slice of one tap.  Operands go global -> LDS by
-// `global_load_lds_dwordx4` (no staging registers, no ds_write), two stages in flight while one is read (a hand-counted REGISTER
-// ring is not safe: the register allocator may copy a destination that is still in flight, tools/check/asm_rings.py).  An LDS-DMA has no register destination; its completion is counted by hand (`s_waitcnt vmcnt(N)`,
-// N = DMA instructions this wave issued after the stage it needs; vector-memory operations retire in order).
+// LDS-DMA ring variant of conv_tiled_kernel (bf16, round 4): 256 pixel rows x BN channels per workgroup; EIGHT COMPUTE WAVES
+// (4 x 2, wave tile 64 x BN/2) AND TWO DMA WAVES (640 threads), a ring of STAGES slots of one 128-byte K slice of one tap.
+//   * Operands go global -> LDS by `global_load_lds_dwordx4` (no staging registers, no ds_write), two stages in flight while one
+//     is read.  A hand-counted REGISTER ring is not safe (the register allocator may copy a destination that is still in flight,
+//     tools/check/asm_rings.py); an LDS-DMA has no register destination, its completion is counted by hand (`s_waitcnt vmcnt(N)`,
+//     N = DMA instructions the wave issued after the stage it needs; vector-memory operations retire in order).
+//   * The DMA waves do nothing else: in-kernel stamps (tools/diag/conv_stamp.py) showed a stage's 48 requests cost the issuing
+//     waves 800-900 cycles (address arithmetic, M0 set-up, ~50 cycles of issue per 64-address DMA) -- as much as the stage's matrix
+//     work.  Issued by all compute waves they stopped every matrix pipe behind each stage barrier; issued by the second compute
+//     wave of every SIMD they serialised that SIMD's two waves (each alone on the pipe runs at ~25 cycles per MFMA: its fragment
+//     reads leave issue bubbles that only ANOTHER wave's MFMAs fill).  Two extra waves with no accumulators take the requests off
+//     the compute waves altogether.
+//   * Compute waves: fragments are read into registers HALF A STAGE ahead of their MFMAs (set 0 = first 32-deep k-step of a stage,
+//     set 1 = second), one read between every two matrix instructions, one barrier per stage.
 // A DMA instruction moves 1 KB = 8 LDS rows of 128 B; lane l fills physical 16-byte slot (l & 7) of row (l >> 3), so it FETCHES
 // the logical chunk (l & 7) ^ (row & 7): the LDS image is the XOR-swizzled one conv_tiled_kernel's fragment reads expect
 // (conflict-free under the ds_read_b128 lane groups of CDNA4).  Source rows are clamped to the last pixel row (rows >= P are
 // never stored), so the guard rows the 128-row kernel needs are enough.
 template <int BN, int STAGES>
-__global__ __launch_bounds__(512, 1) void conv_dma_kernel(ConvArgs g) {
+__global__ __launch_bounds__(640, 1) void conv_dma_kernel(ConvArgs g) {
   typedef bf16_t T;
   typedef typename Frag<T>::type frag;
   constexpr int BM = 256, NJ = BN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  // Only the second wave of every SIMD (waves 4-7) requests operands: behind the stage barrier the first waves go straight to
-  // their matrix instructions while the second ones spend ~300 cycles on scalar bookkeeping and twelve DMA issues, then multiply
-  // while the first ones wait at the next barrier -- the SIMD's matrix pipe sees one stream after the other instead of two idle
-  // and then two contending (counters on a 512-channel layer: pipe busy 0.33, waves issue-stalled 0.36, 87 scalar instructions per
-  // wave and stage; profiles/r04_c3_conv_counters.txt).  CONV_DMA_PRODUCERS=8: every wave requests its share (first version).
-#ifndef CONV_DMA_PRODUCERS
-#define CONV_DMA_PRODUCERS 4
-#endif
-  constexpr int NPW = BN == 256 ? 8 : CONV_DMA_PRODUCERS;         // (the 256-channel tile has no registers to spare for 16 row pointers)
-  constexpr int NA = A_BYTES / 1024 / NPW, NB = B_BYTES / 1024 / NPW, NDMA = NA + NB;  // 1 KB pieces per producer wave and stage
-  static_assert(NB >= 1 && STAGES >= 2 && STAGES <= 4 && (NPW == 4 || NPW == 8) && 2 * NDMA <= 63, "ring shape");
+  constexpr int NDW = 2;                                           // DMA waves (waves 8, 9)
+  constexpr int NPIECE = STAGE_BYTES / 1024, NDMA = NPIECE / NDW;  // 1 KB pieces per stage / per DMA wave and stage
+  constexpr int APIECE = A_BYTES / 1024;
+  static_assert(NPIECE % NDW == 0 && (STAGES == 2 || STAGES == 3) && (STAGES - 1) * NDMA <= 63, "ring shape (vmcnt is a six-bit count)");
   extern __shared__ __attribute__((aligned(1024))) unsigned char cd_lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool producer = wave >= 8 - NPW;
-  const int pw = producer ? wave - (8 - NPW) : 0;
+  const bool dma_wave = wave >= 8;
+  const int wm = (wave & 7) >> 1, wn = wave & 1;
   const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;        // XCD-aware order, as in conv_tiled_kernel
   const unsigned xcd = lin & 7, jj = lin >> 3;
   const long m0 = (long)((jj / gridDim.y) * 8 + xcd) * BM;
   const int n0 = (int)(jj % gridDim.y) * BN;
   if (m0 >= g.P) return;
-  const long ldw = (long)g.ntap * g.Cin;
   const int kc = g.Cin / 64;
   const int nstage = g.ntap * kc;
-  const int r_in = lane >> 3, pc = lane & 7, lc = pc ^ r_in;       // (8 * piece is a multiple of 8: row & 7 == r_in)
-  const unsigned char* srcA[NA];
-  const unsigned char* srcB[NB];
-#pragma unroll
-  for (int h = 0; h < NA; ++h) {
-    long row = m0 + 8 * (NA * pw + h) + r_in;
-    row = row < g.P ? row : g.P - 1;
-    srcA[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.A) + row * g.lda + lc * 8);
-  }
-#pragma unroll
-  for (int h = 0; h < NB; ++h)
-    srcB[h] = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.Wp) + (long)(n0 + 8 * (NB * pw + h) + r_in) * ldw + lc * 8);
-  const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)cd_lds;
-  auto dma = [&](const unsigned char* src, unsigned ldst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(ldst) : "memory");
-  };
-  int ftap = 0, fcc = 0;                                           // (tap, K slice) of the next stage to request
-  auto fill = [&](int slot) {
-    if (!producer) return;
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
-    const long aoff = ((long)tap_offset(g, ftap) * g.lda + fcc * 64) * 2;
-    const long boff = ((long)(ftap * kc + fcc) * 64) * 2;
-#pragma unroll
-    for (int h = 0; h < NA; ++h) dma(srcA[h] + aoff, l + (NA * pw + h) * 1024);
-#pragma unroll
-    for (int h = 0; h < NB; ++h) dma(srcB[h] + boff, l + A_BYTES + (NB * pw + h) * 1024);
-    if (++fcc == kc) { fcc = 0; ++ftap; }
-  };
-  auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
-    const int c = 4 * ks + q;
-    return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
-  };
   f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // Software pipeline (round 4, second version): fragments are read into registers HALF A STAGE ahead of their MFMAs (set 0 holds
-  // the first 32-deep k-step of a stage, set 1 the second), so the matrix instructions of a half wait for nothing that was
-  // issued in that half:
-  //   half 1:  read set 1 <- (st, k-step 1)                      | 16 MFMAs on set 0 = (st, k-step 0)
-  //   half 2:  wait for this wave's DMA pieces of stage st+1, lgkmcnt(0) (set 1 has landed; the wave has read all of stage st),
-  //            barrier  -> stage st+1 visible to everyone, slot of stage st free: refill it with stage st+3 (three slots: two
-  //            stages in flight while one is read)
-  //            read set 0 <- (st+1, k-step 0)                    | 16 MFMAs on set 1 = (st, k-step 1)
-  // One barrier per stage, as before.  The sizing builds said where the register-staged kernel loses: with NO operand fetch
-  // behind its first stage it still needs 0.82 of its time (a deep layer: 0.207 of 0.252 ms, 2.6x its MFMA time) -- fragment
-  // reads, their waits and the stage barrier between the matrix instructions, not the fetches.
-  constexpr int LGKM0 = 0xC07F;                                   // s_waitcnt lgkmcnt(0); vmcnt / expcnt untouched (gfx9 encoding)
-  auto read_set = [&](frag (&a)[4], frag (&b)[NJ], int slot, int ks) {
-    const unsigned char* ta = cd_lds + (size_t)slot * STAGE_BYTES;
-    const unsigned char* tb = ta + A_BYTES;
+
+  if (dma_wave) {
+    // ------------------------------------------------------------------------------------------ the two DMA waves
+    const int dw = wave - 8;
+    const long ldw = (long)g.ntap * g.Cin;
+    const int r_in = lane >> 3, pc = lane & 7, lc = pc ^ r_in;     // (8 * piece is a multiple of 8: row & 7 == r_in)
+    const unsigned char* src[NDMA];                                // this wave's pieces: NDMA * dw + h; pieces < APIECE are A rows
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = lfrag(ta, wm * 64 + 16 * i + n, ks);
+    for (int h = 0; h < NDMA; ++h) {
+      const int pz = NDMA * dw + h;                                // (wave-uniform, but not a compile-time constant: both branches below)
+      long row = m0 + 8 * pz + r_in;
+      row = row < g.P ? row : g.P - 1;
+      const unsigned char* pa = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.A) + row * g.lda + lc * 8);
+      const unsigned char* pb = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(g.Wp) + (long)(n0 + 8 * (pz - APIECE) + r_in) * ldw + lc * 8);
+      src[h] = pz < APIECE ? pa : pb;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long)(lds_void*)cd_lds;
+    auto dma = [&](const unsigned char* sp, unsigned ldst) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(sp), "s"(ldst) : "memory");
+    };
+    int ftap = 0, fcc = 0;                                         // (tap, K slice) of the next stage to request
+    auto fill = [&](int slot) {
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * STAGE_BYTES);
+      const long aoff = ((long)tap_offset(g, ftap) * g.lda + fcc * 64) * 2;
+      const long boff = ((long)(ftap * kc + fcc) * 64) * 2;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b[j] = lfrag(tb, wn * (BN / 2) + 16 * j + n, ks);
-  };
-  auto mma_set = [&](const frag (&a)[4], const frag (&b)[NJ]) {
+      for (int h = 0; h < NDMA; ++h) {
+        const int pz = NDMA * dw + h;
+        dma(src[h] + (pz < APIECE ? aoff : boff), l + pz * 1024);  // (the stage image is [A pieces | B pieces]: piece pz at pz KB)
+      }
+      if (++fcc == kc) { fcc = 0; ++ftap; }
+    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
-  };
-  static_assert(STAGES == 2 || STAGES == 3, "the pipeline below is written for rings of two or three slots");
-#pragma unroll
-  for (int s0 = 0; s0 < STAGES; ++s0)
-    if (s0 < nstage) fill(s0);
-  frag a0[4], b0[NJ], a1[4], b1[NJ];
-  // stage 0: DMAs requested after it: stages 1 .. STAGES-1 (where they exist)
-  if (producer) {                                  // (the other waves learn it from the barrier)
+    for (int s0 = 0; s0 < STAGES; ++s0)
+      if (s0 < nstage) fill(s0);
+    // stage 0: requested after it: stages 1 .. STAGES-1 (where they exist)
     if (STAGES == 3 && nstage > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
     else if (nstage >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  asm volatile("s_barrier" ::: "memory");
-  read_set(a0, b0, 0, 0);
-  __builtin_amdgcn_s_waitcnt(LGKM0);
-  int slot = 0;
-  for (int st = 0; st < nstage; ++st) {
-    const bool more = st + 1 < nstage;
-    const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
-    // ---- half 1
-    read_set(a1, b1, slot, 1);
-    __builtin_amdgcn_sched_barrier(0);             // the reads go out in front of the matrix instructions, not behind them
-    mma_set(a0, b0);                               // (set 0 was waited for at the end of the previous half: no wait here)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- half 2
-    if (more && producer) {                        // (two slots: stage st+2 is requested BEHIND the barrier below, nothing is younger)
-      if (STAGES == 3 && st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // stage st+2 may still be in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_waitcnt(LGKM0);             // set 1 landed: this wave has read everything it needs of stage st
-    asm volatile("s_barrier" ::: "memory");        // every wave: stage st+1 landed, slot of stage st no longer read
-#ifndef CONV_DIAG_NOFILL   /* sizing build (timing only): no operand fetch behind the three prologue stages */
-    if (st + STAGES < nstage) fill(slot);
+    asm volatile("s_barrier" ::: "memory");                        // (B0) stage 0 visible
+    int slot = 0;
+    for (int st = 0; st < nstage; ++st) {
+      if (st + 1 < nstage) {                                       // stage st+1 landed? (STAGES == 2: st+2 is requested behind the barrier)
+        if (STAGES == 3 && st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");                      // (B1..) stage st+1 visible; every compute wave has read all of stage st
+#ifndef CONV_DIAG_NOFILL   /* sizing build (timing only): no operand fetch behind the prologue stages */
+      if (st + STAGES < nstage) fill(slot);
 #endif
-    if (more) read_set(a0, b0, nslot, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_set(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    // set 0 has had sixteen MFMAs to land: an explicit wait HERE costs nothing and leaves hipcc's wait-count pass with nothing
-    // pending across the loop edge (without it the pass put lgkmcnt(0) between half 1's reads and its MFMAs: set 1's reads exposed)
+      slot = slot == STAGES - 1 ? 0 : slot + 1;
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ the eight compute waves
+    auto lfrag = [&](const unsigned char* base, int row, int ks) -> frag {
+      const int c = 4 * ks + q;
+      return *reinterpret_cast<const frag*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    };
+    constexpr int LGKM0 = 0xC07F;                                  // s_waitcnt lgkmcnt(0); vmcnt / expcnt untouched (gfx9 encoding)
+    auto read_set = [&](frag (&a)[4], frag (&b)[NJ], int slot, int ks) {
+      const unsigned char* ta = cd_lds + (size_t)slot * STAGE_BYTES;
+      const unsigned char* tb = ta + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = lfrag(ta, wm * 64 + 16 * i + n, ks);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = lfrag(tb, wn * (BN / 2) + 16 * j + n, ks);
+    };
+    auto mma_set = [&](const frag (&a)[4], const frag (&b)[NJ]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+    };
+    frag a0[4], b0[NJ], a1[4], b1[NJ];
+    asm volatile("s_barrier" ::: "memory");                        // (B0) stage 0 visible (the DMA waves waited for it)
+    read_set(a0, b0, 0, 0);
     __builtin_amdgcn_s_waitcnt(LGKM0);
-    slot = nslot;
+    int slot = 0;
+#ifdef CONV_STAMP   /* diagnostic build (tools/diag/conv_stamp.py): cycles per phase of wave 0 of workgroup 0 */
+    unsigned long long sacc[5] = {0, 0, 0, 0, 0}, slast = __builtin_readcyclecounter();
+#define CST(i) { const unsigned long long nw = __builtin_readcyclecounter(); sacc[i] += nw - slast; slast = nw; }
+#else
+#define CST(i)
+#endif
+    for (int st = 0; st < nstage; ++st) {
+      const int nslot = slot == STAGES - 1 ? 0 : slot + 1;
+      // ---- half 1: read set 1 <- (st, k-step 1) between the 16 MFMAs on set 0 = (st, k-step 0)
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(a1, b1, slot, 1);
+      mma_set(a0, b0);                             // (set 0 was waited for at the end of the previous half: no wait here)
+#pragma unroll
+      for (int k = 0; k < 4 + NJ; ++k) {           // one fragment read between every two matrix instructions
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NJ) / (4 + NJ), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      CST(0)
+      // ---- half 2: everything of stage st is in registers -> barrier -> read set 0 <- (st+1, k-step 0) between the MFMAs on set 1
+      __builtin_amdgcn_s_waitcnt(LGKM0);
+      CST(1)
+      asm volatile("s_barrier" ::: "memory");      // (B1..) stage st+1 visible; the slot of stage st may be refilled
+      CST(2)
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(a0, b0, nslot, 0);                  // (behind the last stage: a harmless read of a stale slot -- unconditional, so that
+      mma_set(a1, b1);                             //  the reads and the matrix instructions share a basic block and interleave)
+#pragma unroll
+      for (int k = 0; k < 4 + NJ; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * NJ) / (4 + NJ), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // set 0 has had sixteen MFMAs to land: an explicit wait HERE costs nothing and leaves hipcc's wait-count pass with nothing
+      // pending across the loop edge (without it the pass put lgkmcnt(0) between half 1's reads and its MFMAs)
+      __builtin_amdgcn_s_waitcnt(LGKM0);
+      CST(4)
+      slot = nslot;
+    }
+#ifdef CONV_STAMP
+    if (blockIdx.x == 0 && blockIdx.y == 0 && g.stat_part && tid == 0) {
+      unsigned long long* dbgp = reinterpret_cast<unsigned long long*>(g.stat_part + (size_t)((g.P + 127) / 128) * 2 * g.ldp);   // behind the last tile's sums
+      for (int i = 0; i < 5; ++i) dbgp[i] = sacc[i];
+      dbgp[5] = (unsigned long long)nstage;
+    }
+#endif
+#undef CST
   }
   T* C = reinterpret_cast<T*>(g.C);
   float st1[NJ], st2[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) st1[j] = st2[j] = 0.f;
+  if (!dma_wave) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long row = m0 + wm * 64 + 16 * i + 4 * q + r;
-      if (!interior(row, g.P, g.H, g.W)) continue;
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + 16 * i + 4 * q + r;
+        if (!interior(row, g.P, g.H, g.W)) continue;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * (BN / 2) + 16 * j + n;
-        if (col >= g.Cout) continue;
-        float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
-        if (g.scale) {
-          v = v * g.scale[col] + g.shift[col];
-          v = v > 0.f ? v : g.slope * v;
+        for (int j = 0; j < NJ; ++j) {
+          const int col = n0 + wn * (BN / 2) + 16 * j + n;
+          if (col >= g.Cout) continue;
+          float v = acc[i][j][r] + (g.bias ? g.bias[col] : 0.f);
+          if (g.scale) {
+            v = v * g.scale[col] + g.shift[col];
+            v = v > 0.f ? v : g.slope * v;
+          }
+          const T o = from_f32<T>(v);
+          C[row * g.ldc + col] = o;
+          const float vo = to_f32<T>(o);
+          st1[j] += vo;
+          st2[j] += vo * vo;
         }
-        const T o = from_f32<T>(v);
-        C[row * g.ldc + col] = o;
-        const float vo = to_f32<T>(o);
-        st1[j] += vo;
-        st2[j] += vo * vo;
       }
-    }
+  }
   if (g.stat_part) {
     // the workgroup covers TWO 128-row statistics tiles (waves wm = 0,1 and wm = 2,3): same sums in the same order as
-    // conv_tiled_kernel's, tile by tile
+    // conv_tiled_kernel's, tile by tile.  (All ten waves take the two barriers.)
     __syncthreads();                                             // the ring is free: every wave has left the main loop
     float* sp = reinterpret_cast<float*>(cd_lds);                // [wm][stat][BN]
+    if (!dma_wave) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float a = st1[j], b = st2[j];
-      a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-      b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-      if (q == 0) {
-        sp[(wm * 2 + 0) * BN + wn * (BN / 2) + 16 * j + n] = a;
-        sp[(wm * 2 + 1) * BN + wn * (BN / 2) + 16 * j + n] = b;
+      for (int j = 0; j < NJ; ++j) {
+        float a = st1[j], b = st2[j];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) {
+          sp[(wm * 2 + 0) * BN + wn * (BN / 2) + 16 * j + n] = a;
+          sp[(wm * 2 + 1) * BN + wn * (BN / 2) + 16 * j + n] = b;
+        }
       }
     }
     __syncthreads();
@@ -1307,30 +1337,18 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
     // layers whose channel count gives 128-wide tiles (default, NPPC_CONV_DMA unset or 3): bit-identical to the register-staged
     // kernel (tests/test_inpaint_gpu.py), 5-7 % faster on the >= 128-channel layers of C3, step 26.05 -> 25.85 ms.  The
     // 64-channel tiles stay on the register-staged kernel (the ring kernel is 20-28 % slower there: one 8-wave workgroup per CU
-    // against two 4-wave ones).  NPPC_CONV_DMA=0: register-staged everywhere; 1: ring kernel wherever its grid fills the chip;
-    // 2: as 1 with 256-channel tiles where possible (profiles/r04_c3_conv_dma_ab.txt).
+    // against two 4-wave ones).  NPPC_CONV_DMA=0: register-staged everywhere; 1: ring kernel wherever its grid fills the chip
+    // (profiles/r04_c3_conv_dma_ab.txt).
     const char* cd = getenv("NPPC_CONV_DMA");
     if (!cd || !cd[0]) cd = "3";
-    const bool use_dma = cd[0] == '1' || cd[0] == '2' || (cd[0] == '3' && Np % 128 == 0);
+    const bool use_dma = cd[0] == '1' || (cd[0] == '3' && Np % 128 == 0);
     if (use_dma && prec == NPPC_PREC_BF16 && Cin % 64 == 0) {
-      // NPPC_CONV_DMA=2: 256-channel tiles (wave tile 64 x 128, two ring slots) where Np allows -- half the LDS bytes and half the
-      // barriers per MFMA of the 128-channel tile
-      const int bn = cd[0] != '2' ? (Np % 128 == 0 ? 128 : 64) : (Np % 256 == 0 ? 256 : (Np % 128 == 0 ? 128 : 64));
+      const int bn = Np % 128 == 0 ? 128 : 64;
       const long tiles = (long)ceil_div(g.P, 256) * (Np / bn);
       const char* mt = getenv("NPPC_CONV_DMA_MIN_TILES");          // (tests lower it to run small, ragged shapes through the ring kernel)
       if (tiles >= (mt ? atol(mt) : 256L)) {
         dim3 grid(round_up(ceil_div(g.P, 256), 8), Np / bn);
-        if (bn == 256) {
-          constexpr int smem = 2 * (256 + 256) * 128;
-          static bool attr = false;
-          if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    smem) != hipSuccess)
-              return NPPC_ELAUNCH;
-            attr = true;
-          }
-          hipLaunchKernelGGL((conv_dma_kernel<256, 2>), grid, dim3(512), smem, st, g);
-        } else if (bn == 128) {
+        if (bn == 128) {
           constexpr int smem = 3 * (256 + 128) * 128;
           static bool attr = false;
           if (!attr) {
@@ -1339,7 +1357,7 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
               return NPPC_ELAUNCH;
             attr = true;
           }
-          hipLaunchKernelGGL((conv_dma_kernel<128, 3>), grid, dim3(512), smem, st, g);
+          hipLaunchKernelGGL((conv_dma_kernel<128, 3>), grid, dim3(640), smem, st, g);
         } else {
           constexpr int smem = 3 * (256 + 64) * 128;
           static bool attr = false;
@@ -1349,7 +1367,7 @@ static int conv_fwd_impl(int prec, const void* A, long lda, const void* Wp, void
               return NPPC_ELAUNCH;
             attr = true;
           }
-          hipLaunchKernelGGL((conv_dma_kernel<64, 3>), grid, dim3(512), smem, st, g);
+          hipLaunchKernelGGL((conv_dma_kernel<64, 3>), grid, dim3(640), smem, st, g);
         }
         NPPC_CHECK_LAUNCH();
         return NPPC_OK;
